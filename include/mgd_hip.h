@@ -1,0 +1,234 @@
+/*
+ * libmgd_hip.so — C-ABI of the MI355X-native MultiGridDet hot path (gfx950 / CDNA4).
+ *
+ * The reference (solufast-cvprojects/multigriddet) is pure Python on TensorFlow and has no
+ * FFI/plugin boundary of its own; its drop-in boundary is the Python API.
+ * Every entry point below therefore replaces a TF/Keras op or a numpy routine of the reference;
+ * the reference interface each one stands in for is cited as file:line (paths relative to the
+ * reference root).  The host-side mirror of the reference's Python API lives in
+ * `multigriddet_amd/` and calls these through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer unless the name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - no hidden allocation: scratch is a caller-provided workspace, sized by a *_workspace_size query;
+ *   - return value 0 = ok, negative = MGD_E*; `mgd_last_error()` returns a thread-local message;
+ *   - tensors are NHWC; bf16 is the 16-bit brain float (uint16_t storage); sizes are element counts.
+ */
+#ifndef MGD_HIP_H
+#define MGD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGD_OK 0
+#define MGD_EINVAL (-1)  /* bad argument (shape, alignment, unsupported option) */
+#define MGD_ELAUNCH (-2) /* HIP launch failure                                   */
+#define MGD_ENOSPC (-3)  /* workspace too small                                  */
+
+const char* mgd_last_error(void);
+int mgd_version(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * Convolution engine (implicit GEMM on bf16 MFMA, fp32 accumulate).
+ * Replaces: Keras Conv2D as used by DarknetConv2D / DarknetConv2D_BN_Leaky
+ *           (multigriddet/models/layers.py:43-49, 88-95), its autodiff (dgrad, wgrad), and
+ *           ZeroPadding2D(((1,0),(1,0))) + 'valid' stride-2 conv (models/backbones/darknet.py:33-34).
+ *
+ * One generic "gather-GEMM" descriptor covers forward, data-gradient (incl. the four output-parity
+ * classes of the stride-2 transposed conv) and 1x1: for iteration point (n, i, j) and tap t the
+ * source pixel is (i*in_stride + dh[t], j*in_stride + dw[t]) (zero outside the source) and the
+ * destination pixel is (i*out_stride + out_off_h, j*out_stride + out_off_w).
+ *   dst[n, ., ., co] = sum_{t, ci} src[n, ., ., ci] * wpk[co][t*Ci + ci]  (+ bias[co]) (+ addend)
+ * `wpk` is a packed bf16 weight image [Co_pad][K_pad] produced by mgd_pack_weights.
+ * Optional epilogues: per-channel sum / sum-of-squares of the (bf16-rounded) result into
+ * `stats[(block % stats_replicas)][2][Co]` for training-mode BatchNorm; fp32 output.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mgd_conv_desc {
+  const void* src;      /* bf16 [N, Hs, Ws, Ci]                                   */
+  const void* wpk;      /* bf16 packed weights [Co_pad][K_pad]                    */
+  void* dst;            /* bf16 (or f32 if dst_f32) [N, Hd, Wd, Co]               */
+  const float* bias;    /* optional f32 [Co]                                      */
+  const void* addend;   /* optional bf16 [N, Hd, Wd, Co], added before the store  */
+  float* stats;         /* optional f32 [stats_replicas][2][Co], accumulated      */
+  int32_t N, Hs, Ws, Ci;
+  int32_t Hg, Wg;       /* iteration grid                                         */
+  int32_t Hd, Wd, Co;
+  int32_t in_stride, out_stride, out_off_h, out_off_w;
+  int32_t ntaps;
+  int32_t dh[9], dw[9];
+  int32_t K_pad, Co_pad; /* of wpk                                                */
+  int32_t dst_f32;
+  int32_t stats_replicas;
+} mgd_conv_desc;
+
+int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream);
+
+/* Weight gradient: dW[co][t][ci] += sum_p dy[p][co] * src[p (+) tap t][ci]   (fp32 atomics).
+ * Replaces the Conv2D kernel gradient of Keras autodiff (layers.py:43-49).  Geometry fields have
+ * the forward conv's meaning (src = forward input, dy = gradient of the forward output, whose
+ * pixel grid is the iteration grid Hg x Wg; in_stride, dh, dw as in the forward descriptor).
+ * `dw` is fp32 [Co][ntaps][Ci] (the master OHWI layout) and must be zeroed by the caller before the
+ * first accumulation of a step. `splits` = number of pixel-range slices (>=1). */
+typedef struct mgd_wgrad_desc {
+  const void* src;  /* bf16 [N, Hs, Ws, Ci]     */
+  const void* dy;   /* bf16 [N, Hg, Wg, Co]     */
+  float* dw;        /* f32 [Co][ntaps][Ci]      */
+  int32_t N, Hs, Ws, Ci, Hg, Wg, Co;
+  int32_t in_stride, ntaps;
+  int32_t dh[9], dw_off[9];
+  int32_t splits;
+} mgd_wgrad_desc;
+
+int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream);
+
+/* Stem conv 3x3, Cin=3 -> Cout=32, stride 1, 'same' (models/backbones/darknet.py:21): direct
+ * (non-MFMA, HBM-bound) kernels.  image f32 [N,H,W,3]; w f32 [32][3][3][3] (OHWI); y bf16 [N,H,W,32]. */
+int mgd_stem_fwd(const float* image, const float* w, void* y, float* stats, int stats_replicas, int N, int H,
+                 int W, void* stream);
+int mgd_stem_wgrad(const float* image, const void* dy, float* dw, int N, int H, int W, void* stream);
+
+/* Pack fp32 master weights W[Co][T][Ci] (OHWI) into a bf16 gather-GEMM image.
+ * out[r][t'*Cin' + c] = transpose ? W[c][src_tap[t']][r] : W[r][src_tap[t']][c], zero padded to
+ * [rows_pad][K_pad].  (transpose=1 builds data-gradient images.) */
+int mgd_pack_weights(const float* w, void* out, int Co, int T, int Ci, int transpose, int ntaps_out,
+                     const int32_t* src_tap_host, int rows_pad, int K_pad, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * BatchNorm (training mode, Keras defaults eps 1e-3 / momentum 0.99) + LeakyReLU(0.1) + residual
+ * Replaces: BatchNormalization() + LeakyReLU(alpha=0.1) (layers.py:94-95), Add (darknet.py:39)
+ * and their gradients.
+ * ---------------------------------------------------------------------------------------------- */
+/* stats [R][2][C] -> mean,var; scale=gamma*rsqrt(var+eps), shift=beta-mean*scale; saves
+ * mean/invstd for backward; moving = moving*momentum + batch*(1-momentum).  If training==0 the
+ * moving statistics are used and nothing is updated. */
+int mgd_bn_finalize(const float* stats, int replicas, int C, float count, const float* gamma, const float* beta,
+                    float* moving_mean, float* moving_var, float* scale, float* shift, float* save_mean,
+                    float* save_invstd, float eps, float momentum, int training, void* stream);
+/* a = leaky(y*scale+shift) (+ residual); bf16 [P][C] */
+int mgd_bn_act_fwd(const void* y, const float* scale, const float* shift, const void* residual, void* a,
+                   int64_t P, int C, float slope, void* stream);
+/* sums[R][2][C] += { sum dyh, sum dyh*yhat },  dyh = da * leaky'(y*scale+shift) */
+int mgd_bn_act_bwd_reduce(const void* da, const void* y, const float* scale, const float* shift,
+                          const float* save_mean, const float* save_invstd, float* sums, int replicas,
+                          int64_t P, int C, float slope, void* stream);
+/* dgamma,dbeta <- sums; dy = scale*(dyh - mean(dyh) - yhat*mean(dyh*yhat));  if frozen: dy = scale*dyh */
+int mgd_bn_act_bwd_apply(const void* da, const void* y, const float* scale, const float* shift,
+                         const float* save_mean, const float* save_invstd, const float* sums, int replicas,
+                         float* dgamma, float* dbeta, void* dy, int64_t P, int C, float slope, int frozen,
+                         void* stream);
+
+/* UpSampling2D(2) nearest + Concatenate([up, skip]) (heads/multigrid_head.py:296-298) and backward. */
+int mgd_upsample_concat_fwd(const void* u, const void* skip, void* out, int N, int h, int w, int Cu, int Cs,
+                            void* stream);
+int mgd_upsample_concat_bwd(const void* dout, void* du, void* dskip, int N, int h, int w, int Cu, int Cs,
+                            void* stream);
+/* dbias[c] = sum_p dy[p][c] for the three linear prediction convs (multigrid_head.py:71). */
+int mgd_bias_grad(const void* dy_bf16, float* dbias, int64_t P, int C, void* stream);
+int mgd_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+int mgd_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
+
+/* Adam with Keras semantics (config/model_builder.py:86-96): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+ * p -= lr_t*m/(sqrt(v)+eps).  grad_scale multiplies g first (1/world for DP averaging).
+ * weight_decay > 0 gives AdamW (decoupled, Keras: p -= lr*wd*p). */
+int mgd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int step, float grad_scale, float weight_decay, void* stream);
+int mgd_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, float momentum, int nesterov,
+                 float grad_scale, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * 3x3 multi-grid y_true target builder.
+ * mode 0 (T1) replaces tf_preprocess_true_boxes (multigriddet/data/generators.py:2696-3390);
+ * mode 1 (T2) replaces preprocess_true_boxes      (multigriddet/data/generators.py:3393-3473).
+ * boxes f32 [B][M][5] (x1,y1,x2,y2,cls); anchors f32 [L][A][2]; y_true[l] f32 [B][gh_l][gw_l][5+A+C]
+ * (fully written, zeros included).  assign (optional) int32 [B][M][4] = layer, anchor, row, col.
+ * ---------------------------------------------------------------------------------------------- */
+size_t mgd_build_targets_workspace_size(int B, int M, int L, const int32_t* grid_hw_host);
+int mgd_build_targets(const float* boxes, int B, int M, const float* anchors, int L, int A, int C, int in_h,
+                      int in_w, const int32_t* grid_hw_host, float* const* y_true_host, int32_t* assign,
+                      int mode, void* ws, size_t ws_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * MultiGridLoss forward + backward (multigriddet/losses/multigrid_loss.py:233-443 and helpers
+ * :445-1043).  One call per step handles all L scales.  components[8] (device) receives
+ * {loc, obj, anchor(pre-scaled), cls, consensus_coord, consensus_obj, consensus_cls, total}.
+ * grad_f32[l] / grad_bf16[l] (either may be NULL) receive d total / d y_pred[l].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mgd_loss_cfg {
+  int32_t L, A, C, B;
+  int32_t in_h, in_w;
+  int32_t grid_h[4], grid_w[4];
+  float anchors[4][8][2];
+  float ignore_thresh, label_smoothing;
+  int32_t loss_option;
+  float coord_scale, object_scale, no_object_scale, class_scale, anchor_scale;
+  int32_t norm_batch, norm_positives, norm_grid; /* multiplicities of each entry in loss_normalization */
+  int32_t use_iou_aware_objectness;
+  float iou_objectness_power, iou_objectness_ratio;
+  float trainable_nms_weight, trainable_nms_power;
+  int32_t use_consensus_loss;
+  float consensus_iou_power, consensus_min_iou, consensus_coord_scale, consensus_obj_scale,
+      consensus_class_scale, consensus_center_tolerance;
+  int32_t consensus_stop_gradient;
+  int32_t use_focal_loss; /* 0 = BCE, 1 = sigmoid focal (losses/focal_loss.py:40-77) */
+  float focal_alpha, focal_gamma;
+  float grad_out_scale;   /* multiplies the gradient only (loss scaling); 1.0 normally */
+} mgd_loss_cfg;
+
+size_t mgd_loss_workspace_size(const mgd_loss_cfg* cfg);
+int mgd_loss_fwd_bwd(const mgd_loss_cfg* cfg, const float* const* y_pred_host, const float* const* y_true_host,
+                     const float* class_weights, float* const* grad_f32_host, void* const* grad_bf16_host,
+                     float* components, void* ws, size_t ws_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Decode + correct_boxes + confidence filter (multigriddet/postprocess/multigrid_decode.py:100-235,
+ * 262-283) and greedy / soft NMS + top-k + xyxy (postprocess/nms.py:83-385,
+ * multigrid_decode.py:300-345, 397-422).  Batched over images.
+ * cand layout per image: boxes f32 [cap][4] (top-left xywh, image px), score f32 [cap], cls i32 [cap],
+ * count i32.  Candidates are emitted in the reference's row order (scale-major, then cell).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mgd_decode_cfg {
+  int32_t L, A, C, B;
+  int32_t in_h, in_w;
+  int32_t grid_h[4], grid_w[4];
+  float anchors[4][8][2];
+  int32_t use_softmax, rescore;
+  float confidence;
+  int32_t cap; /* candidate capacity per image (>= total cells to be safe) */
+} mgd_decode_cfg;
+
+size_t mgd_decode_workspace_size(const mgd_decode_cfg* cfg);
+int mgd_decode(const mgd_decode_cfg* cfg, const float* const* y_pred_host, const float* image_hw /*[B][2] dev*/,
+               float* cand_boxes, float* cand_scores, int32_t* cand_cls, int32_t* cand_count, void* ws,
+               size_t ws_bytes, void* stream);
+
+/* method: 0 = standard/cluster (IoU), 1 = DIoU, 2 = soft (sigma 0.5, score thr 1e-3).
+ * out_boxes i32 [B][max_boxes][4] (xyxy, clipped, floor(v+0.5)) or f32 xywh if !return_xyxy;
+ * out_count[b] = number of detections. */
+size_t mgd_nms_workspace_size(int B, int cap);
+int mgd_nms(const float* cand_boxes, const float* cand_scores, const int32_t* cand_cls,
+            const int32_t* cand_count, int B, int cap, int method, float threshold, int max_boxes,
+            const float* image_hw, int return_xyxy, void* out_boxes, float* out_scores, int32_t* out_cls,
+            int32_t* out_count, void* ws, size_t ws_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * On-device batch augmentation (multigriddet/data/generators.py:561-1009 Mosaic, :1164-1282
+ * GridMask, :1012-1161 MixUp).  Random draws are made on the host by the caller (so that the
+ * oracle can consume the same draws) and passed in as small parameter arrays.
+ * ---------------------------------------------------------------------------------------------- */
+int mgd_mosaic(const float* images, const float* boxes, int B, int S, int M_in, const int32_t* src_idx /*[B][4]*/,
+               const int32_t* crop_xy /*[B][2]*/, float min_wh, float* out_images, float* out_boxes, int M_out,
+               int32_t* overflow, void* stream);
+int mgd_gridmask(float* images, float* boxes, int B, int S, int M, const int32_t* apply /*[B]*/,
+                 const int32_t* d_l_off /*[B][3]: d, l, offset*/, float keep_frac, void* stream);
+int mgd_mixup(const float* images, const float* boxes, int B, int S, int M_in, const int32_t* partner /*[B]*/,
+              const float* lam /*[B]*/, float* out_images, float* out_boxes, int M_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGD_HIP_H */

@@ -1,0 +1,129 @@
+"""ctypes binding of libmgd_hip.so (the C-ABI declared in include/mgd_hip.h).
+
+There is no CPU fallback: importing an op and calling it without the built library, or on a host
+without a GPU, raises.  PyTorch is used only as the device allocator / stream provider.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmgd_hip.so")
+_lib = None
+
+
+class MgdError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("wpk", C.c_void_p), ("dst", C.c_void_p), ("bias", C.c_void_p),
+        ("addend", C.c_void_p), ("stats", C.c_void_p),
+        ("N", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("Ci", C.c_int32),
+        ("Hg", C.c_int32), ("Wg", C.c_int32),
+        ("Hd", C.c_int32), ("Wd", C.c_int32), ("Co", C.c_int32),
+        ("in_stride", C.c_int32), ("out_stride", C.c_int32), ("out_off_h", C.c_int32), ("out_off_w", C.c_int32),
+        ("ntaps", C.c_int32), ("dh", C.c_int32 * 9), ("dw", C.c_int32 * 9),
+        ("K_pad", C.c_int32), ("Co_pad", C.c_int32), ("dst_f32", C.c_int32), ("stats_replicas", C.c_int32),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p),
+        ("N", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("Ci", C.c_int32),
+        ("Hg", C.c_int32), ("Wg", C.c_int32), ("Co", C.c_int32),
+        ("in_stride", C.c_int32), ("ntaps", C.c_int32), ("dh", C.c_int32 * 9), ("dw_off", C.c_int32 * 9),
+        ("splits", C.c_int32),
+    ]
+
+
+class LossCfg(C.Structure):
+    _fields_ = [
+        ("L", C.c_int32), ("A", C.c_int32), ("C", C.c_int32), ("B", C.c_int32),
+        ("in_h", C.c_int32), ("in_w", C.c_int32),
+        ("grid_h", C.c_int32 * 4), ("grid_w", C.c_int32 * 4),
+        ("anchors", (C.c_float * 2) * 8 * 4),
+        ("ignore_thresh", C.c_float), ("label_smoothing", C.c_float),
+        ("loss_option", C.c_int32),
+        ("coord_scale", C.c_float), ("object_scale", C.c_float), ("no_object_scale", C.c_float),
+        ("class_scale", C.c_float), ("anchor_scale", C.c_float),
+        ("norm_batch", C.c_int32), ("norm_positives", C.c_int32), ("norm_grid", C.c_int32),
+        ("use_iou_aware_objectness", C.c_int32),
+        ("iou_objectness_power", C.c_float), ("iou_objectness_ratio", C.c_float),
+        ("trainable_nms_weight", C.c_float), ("trainable_nms_power", C.c_float),
+        ("use_consensus_loss", C.c_int32),
+        ("consensus_iou_power", C.c_float), ("consensus_min_iou", C.c_float),
+        ("consensus_coord_scale", C.c_float), ("consensus_obj_scale", C.c_float),
+        ("consensus_class_scale", C.c_float), ("consensus_center_tolerance", C.c_float),
+        ("consensus_stop_gradient", C.c_int32),
+        ("use_focal_loss", C.c_int32), ("focal_alpha", C.c_float), ("focal_gamma", C.c_float),
+        ("grad_out_scale", C.c_float),
+    ]
+
+
+class DecodeCfg(C.Structure):
+    _fields_ = [
+        ("L", C.c_int32), ("A", C.c_int32), ("C", C.c_int32), ("B", C.c_int32),
+        ("in_h", C.c_int32), ("in_w", C.c_int32),
+        ("grid_h", C.c_int32 * 4), ("grid_w", C.c_int32 * 4),
+        ("anchors", (C.c_float * 2) * 8 * 4),
+        ("use_softmax", C.c_int32), ("rescore", C.c_int32),
+        ("confidence", C.c_float), ("cap", C.c_int32),
+    ]
+
+
+# every symbol include/mgd_hip.h declares
+EXPORTS = [
+    "mgd_last_error", "mgd_version", "mgd_conv_gather_gemm", "mgd_conv_wgrad", "mgd_stem_fwd", "mgd_stem_wgrad",
+    "mgd_pack_weights", "mgd_bn_finalize", "mgd_bn_act_fwd", "mgd_bn_act_bwd_reduce", "mgd_bn_act_bwd_apply",
+    "mgd_upsample_concat_fwd", "mgd_upsample_concat_bwd", "mgd_bias_grad", "mgd_f32_to_bf16", "mgd_bf16_to_f32",
+    "mgd_adam_step", "mgd_sgd_step", "mgd_build_targets_workspace_size", "mgd_build_targets",
+    "mgd_loss_workspace_size", "mgd_loss_fwd_bwd", "mgd_decode_workspace_size", "mgd_decode",
+    "mgd_nms_workspace_size", "mgd_nms", "mgd_mosaic", "mgd_gridmask", "mgd_mixup",
+]
+
+
+def load():
+    """Load the shared library (no GPU needed for this; compute calls need one)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MgdError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C multigriddet_amd/csrc`. There is no CPU fallback for the multigriddet hot path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.mgd_last_error.restype = C.c_char_p
+    for name in ("mgd_build_targets_workspace_size", "mgd_loss_workspace_size", "mgd_decode_workspace_size",
+                 "mgd_nms_workspace_size"):
+        getattr(lib, name).restype = C.c_size_t
+    _lib = lib
+    return lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise MgdError("multigriddet_amd needs an AMD GPU (gfx950); no CPU execution path exists for the hot path")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise MgdError(f"{what}: {load().mgd_last_error().decode()} (code {rc})")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "device pointer must come from a contiguous CUDA tensor"
+    return C.c_void_p(t.data_ptr())
+
+
+def fptr(t):
+    return C.cast(ptr(t), C.POINTER(C.c_float))

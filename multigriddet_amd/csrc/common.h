@@ -1,0 +1,68 @@
+// Shared helpers for libmgd_hip.so (gfx950 only; no other back end is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mgd_hip.h"
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+int mgd_set_error(int code, const char* fmt, ...);
+
+#define MGD_REQUIRE(cond, ...)                        \
+  do {                                                \
+    if (!(cond)) return mgd_set_error(MGD_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+#define MGD_CHECK_LAUNCH(name)                                                              \
+  do {                                                                                      \
+    hipError_t e__ = hipGetLastError();                                                     \
+    if (e__ != hipSuccess) return mgd_set_error(MGD_ELAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 v;
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+  v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of logical
+// tile ids so that neighbouring tiles hit the same L2.  Bijective for any nblk.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+  int q = nblk >> 3, r = nblk & 7, x = b & 7, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

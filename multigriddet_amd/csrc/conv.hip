@@ -1,0 +1,713 @@
+// Convolution engine for gfx950: implicit-GEMM ("gather-GEMM") on v_mfma_f32_16x16x32_bf16.
+//
+// Forward, data-gradient and 1x1 all run through conv_gather_gemm_kernel; the weight gradient has
+// its own kernel (both GEMM operands are strided along the contraction index there, so fragments
+// are fetched with ds_read_b64_tr_b16).  Replaces Keras Conv2D + autodiff as used by
+// DarknetConv2D_BN_Leaky (reference multigriddet/models/layers.py:43-49,88-95).
+//
+// Data layout in HBM: activations NHWC bf16; packed weights bf16 [Co_pad][K_pad], K = tap*Ci + ci;
+// master weights / weight gradients fp32 [Co][taps][Ci] (OHWI).
+//
+// Block = 256 threads = 4 waves (one per SIMD).  MFMA roles: A := weight tile (rows = output
+// channels), B := gathered pixel tile (cols = pixels), so each lane ends with 4 consecutive output
+// channels of one pixel per accumulator tile - 8-byte packed bf16 pieces that are staged through LDS
+// and leave as whole 16-byte/256-byte NHWC rows.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;          // K elements per stage (2 MFMA k-steps of 32)
+constexpr int ROWB = BK * 2;    // bytes per LDS tile row (128)
+
+struct GemmArgs {
+  const bf16_t* src;
+  const bf16_t* wpk;
+  void* dst;
+  const float* bias;
+  const bf16_t* addend;
+  float* stats;
+  int N, Hs, Ws, Ci, Hg, Wg, Hd, Wd, Co;
+  int in_stride, out_stride, out_off_h, out_off_w;
+  int ntaps;
+  unsigned long long tapcode;  // 4 bits per tap: (dh+1) | (dw+1)<<2
+  int K_pad, Co_pad, dst_f32, stats_replicas;
+  int M;        // N*Hg*Wg
+  int tilesC;   // Co_pad / BNC
+  int nblk;
+};
+
+__device__ __forceinline__ int lds_off(int row, int kc) { return row * ROWB + ((kc ^ (row & 7)) << 4); }
+
+template <int WC, int WP, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_gather_gemm_kernel(GemmArgs a) {
+  constexpr int BNC = WC * MT * 16;  // output channels per block
+  constexpr int BMP = WP * NT * 16;  // pixels per block
+  static_assert(WC * WP == 4, "4 waves");
+  static_assert(BMP == 128, "pixel tile fixed at 128");
+  constexpr int WCH = BNC * 8 / 256;  // weight chunks per thread
+  constexpr int XCH = BMP * 8 / 256;  // pixel chunks per thread (4)
+  constexpr int STAGE = (BNC + BMP) * ROWB;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ long long row_dst[BMP];  // destination element offset of each pixel row (-1 = none)
+  __shared__ float colred[2 * 128];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wc = wave / WP, wp = wave % WP;
+
+  const int L = xcd_remap(blockIdx.x, a.nblk);
+  const int tc = L % a.tilesC, tp = L / a.tilesC;
+  const int co0 = tc * BNC;
+  const int pix0 = tp * BMP;
+
+  // ---- per-row destination offsets (used by the epilogue)
+  if (tid < BMP) {
+    int m = pix0 + tid;
+    long long off = -1;
+    if (m < a.M) {
+      int hw = a.Hg * a.Wg;
+      int n = m / hw, rem = m - n * hw;
+      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+      int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
+      off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
+    }
+    row_dst[tid] = off;
+  }
+
+  // ---- per-thread gather state: XCH rows, one k-chunk column
+  const int kc = tid & 7;
+  long long xbase[XCH];
+  int hs0[XCH], ws0[XCH];
+#pragma unroll
+  for (int i = 0; i < XCH; ++i) {
+    int r = (tid >> 3) + 32 * i;
+    int m = pix0 + r;
+    if (m < a.M) {
+      int hw = a.Hg * a.Wg;
+      int n = m / hw, rem = m - n * hw;
+      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+      hs0[i] = ig * a.in_stride;
+      ws0[i] = jg * a.in_stride;
+      xbase[i] = (((long long)n * a.Hs + hs0[i]) * a.Ws + ws0[i]) * a.Ci;
+    } else {
+      hs0[i] = -(1 << 20);
+      ws0[i] = -(1 << 20);
+      xbase[i] = 0;
+    }
+  }
+  int tap = (kc * 8) / a.Ci;
+  int cch = (kc * 8) - tap * a.Ci;
+
+  const bf16_t* wrow[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) {
+    int q = tid + 256 * i;
+    wrow[i] = a.wpk + (long long)(co0 + (q >> 3)) * a.K_pad + (q & 7) * 8;
+  }
+
+  uint4 wreg[WCH], xreg[XCH];
+  auto load_global = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) wreg[i] = *(const uint4*)(wrow[i] + ks * BK);
+    int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
+    int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
+    bool tv = tap < a.ntaps;
+    long long toff = ((long long)dh * a.Ws + dw) * a.Ci + cch;
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      bool v = tv && (unsigned)(hs0[i] + dh) < (unsigned)a.Hs && (unsigned)(ws0[i] + dw) < (unsigned)a.Ws;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if (v) z = *(const uint4*)(a.src + xbase[i] + toff);
+      xreg[i] = z;
+    }
+    cch += BK;
+    while (cch >= a.Ci) {
+      cch -= a.Ci;
+      ++tap;
+    }
+  };
+  auto write_lds = [&](int buf) {
+    unsigned char* wb = smem + buf * STAGE;
+    unsigned char* xb = wb + BNC * ROWB;
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      int q = tid + 256 * i;
+      *(uint4*)(wb + lds_off(q >> 3, q & 7)) = wreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      int r = (tid >> 3) + 32 * i;
+      *(uint4*)(xb + lds_off(r, kc)) = xreg[i];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K_pad / BK;
+  load_global(0);
+  write_lds(0);
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk) load_global(ks + 1);
+    const unsigned char* wb = smem + buf * STAGE;
+    const unsigned char* xb = wb + BNC * ROWB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 wf[MT], xf[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(wb + lds_off((wc * MT + m) * 16 + fr, kk * 4 + fq));
+#pragma unroll
+      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(xb + lds_off((wp * NT + n) * 16 + fr, kk * 4 + fq));
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
+    }
+    if (ks + 1 < nk) write_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS [pixel][channel] -> coalesced NHWC rows
+  const int esz = a.dst_f32 ? 4 : 2;
+  const int EROW = BNC * esz + 16;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    int cl = (wc * MT + m) * 16 + fq * 4;  // first of 4 consecutive channels
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (a.bias) {
+      int c = co0 + cl;
+      if (c + 3 < a.Co) { b0 = a.bias[c]; b1 = a.bias[c + 1]; b2 = a.bias[c + 2]; b3 = a.bias[c + 3]; }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      int pl = (wp * NT + n) * 16 + fr;
+      f32x4 v = acc[m][n];
+      v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+      if (a.dst_f32) {
+        *(f32x4*)(smem + pl * EROW + cl * 4) = v;
+      } else {
+        uint2 p;
+        p.x = pack2bf(v[0], v[1]);
+        p.y = pack2bf(v[2], v[3]);
+        *(uint2*)(smem + pl * EROW + cl * 2) = p;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int rows_valid = min(BMP, a.M - pix0);
+  if (a.stats && !a.dst_f32) {
+    // column sums of the bf16-rounded tile: thread = (column pair, row group), then LDS, then
+    // 2*BNC well-shaped global atomics per block into one of `stats_replicas` copies.
+    constexpr int NCP = BNC / 2, RG = 256 / NCP, RPG = BMP / RG;
+    if (tid < 2 * BNC) colred[tid] = 0.f;
+    __syncthreads();
+    int cp = tid % NCP, rg = tid / NCP;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    int rend = min(rows_valid, (rg + 1) * RPG);
+    for (int r = rg * RPG; r < rend; ++r) {
+      uint32_t u = *(const uint32_t*)(smem + r * EROW + cp * 4);
+      float v0 = __uint_as_float(u << 16), v1 = __uint_as_float(u & 0xffff0000u);
+      s0 += v0; s1 += v1; q0 += v0 * v0; q1 += v1 * v1;
+    }
+    atomicAdd(&colred[2 * cp], s0);
+    atomicAdd(&colred[2 * cp + 1], s1);
+    atomicAdd(&colred[BNC + 2 * cp], q0);
+    atomicAdd(&colred[BNC + 2 * cp + 1], q1);
+    __syncthreads();
+    if (tid < 2 * BNC) {
+      int which = tid / BNC, col = tid - which * BNC;
+      if (co0 + col < a.Co) {
+        int rep = blockIdx.x % a.stats_replicas;
+        atomicAdd(a.stats + ((long long)rep * 2 + which) * a.Co + co0 + col, colred[tid]);
+      }
+    }
+  }
+  const int CPR = BNC * esz / 16;  // 16-byte chunks per row
+  for (int q = tid; q < BMP * CPR; q += 256) {
+    int r = q / CPR, ch = q - r * CPR;
+    long long off = row_dst[r];
+    int c = co0 + ch * (16 / esz);
+    if (off < 0 || c >= a.Co) continue;
+    uint4 v = *(const uint4*)(smem + r * EROW + ch * 16);
+    if (a.dst_f32) {
+      *(uint4*)((float*)a.dst + off + c) = v;
+    } else {
+      if (a.addend) {
+        uint4 ad = *(const uint4*)(a.addend + off + c);
+        float f[8], g[8];
+        unpack8(v, f);
+        unpack8(ad, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += g[j];
+        v = pack8(f);
+      }
+      *(uint4*)((bf16_t*)a.dst + off + c) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient.  dW[co][tap][ci] += sum_p dy[p][co] * src[p (+) tap][ci]
+// LDS tiles are [pixel][channel] exactly as they come from NHWC memory; MFMA fragments need
+// [channel][8 consecutive pixels], fetched with ds_read_b64_tr_b16 (4 pixel rows x 16 channels per
+// 16-lane group, delivered column-major).
+struct WgradArgs {
+  const bf16_t* src;
+  const bf16_t* dy;
+  float* dw;
+  int N, Hs, Ws, Ci, Hg, Wg, Co;
+  int in_stride, ntaps;
+  unsigned long long tapcode;
+  int P;          // N*Hg*Wg
+  int chunk;      // pixels per split (multiple of 64)
+  int splits, tilesCo, tilesCi;
+  float rcp_hw, rcp_w;
+};
+
+__device__ __forceinline__ int tr_swz(int row, int nchunk32) {
+  return ((row & 3) | (((row >> 3) & 1) << 2)) & (nchunk32 - 1);
+}
+
+__device__ __forceinline__ s16x4 ds_read_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+template <int WC, int WI, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int BCO = WC * MT * 16;
+  constexpr int BCI = WI * NT * 16;
+  static_assert(WC * WI == 4, "4 waves");
+  constexpr int RBO = BCO * 2, RBI = BCI * 2;      // row bytes
+  constexpr int CO_CPR = BCO / 8, CI_CPR = BCI / 8;  // 16-byte chunks per row
+  constexpr int OCH = 64 * CO_CPR / 256, ICH = 64 * CI_CPR / 256;  // chunks per thread
+  static_assert(OCH >= 1 && ICH >= 1, "tile too small");
+  constexpr int STAGE = 64 * (RBO + RBI);
+  constexpr int EROW = (BCI + 4) * 4;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave / WI, wi = wave % WI;
+
+  int b = blockIdx.x;
+  const int tco = b % a.tilesCo; b /= a.tilesCo;
+  const int tci = b % a.tilesCi; b /= a.tilesCi;
+  const int tap = b % a.ntaps;
+  const int split = b / a.ntaps;
+  const int co0 = tco * BCO, ci0 = tci * BCI;
+  const int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
+  const int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
+  const int pbeg = split * a.chunk;
+  const int pend = min(a.P, pbeg + a.chunk);
+  const int nk = (pend - pbeg + 63) / 64;
+
+  uint4 oreg[OCH], ireg[ICH];
+  auto load_global = [&](int ks) {
+    const int p0 = pbeg + ks * 64;
+#pragma unroll
+    for (int i = 0; i < OCH; ++i) {
+      int q = tid + 256 * i;
+      int r = q / CO_CPR, ch = q - r * CO_CPR;
+      int p = p0 + r, c = co0 + ch * 8;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if (p < pend && c < a.Co) z = *(const uint4*)(a.dy + (long long)p * a.Co + c);
+      oreg[i] = z;
+    }
+#pragma unroll
+    for (int i = 0; i < ICH; ++i) {
+      int q = tid + 256 * i;
+      int r = q / CI_CPR, ch = q - r * CI_CPR;
+      int p = p0 + r, c = ci0 + ch * 8;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if (p < pend && c < a.Ci) {
+        const int hw = a.Hg * a.Wg;
+        int n = (int)((float)p * a.rcp_hw);
+        int rem = p - n * hw;
+        while (rem < 0) { --n; rem += hw; }
+        while (rem >= hw) { ++n; rem -= hw; }
+        int ig = (int)((float)rem * a.rcp_w);
+        int jg = rem - ig * a.Wg;
+        while (jg < 0) { --ig; jg += a.Wg; }
+        while (jg >= a.Wg) { ++ig; jg -= a.Wg; }
+        int hs = ig * a.in_stride + dh, ws = jg * a.in_stride + dw;
+        if ((unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws)
+          z = *(const uint4*)(a.src + (((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci + c);
+      }
+      ireg[i] = z;
+    }
+  };
+  auto write_lds = [&](int buf) {
+    unsigned char* ob = smem + buf * STAGE;
+    unsigned char* ib = ob + 64 * RBO;
+#pragma unroll
+    for (int i = 0; i < OCH; ++i) {
+      int q = tid + 256 * i;
+      int r = q / CO_CPR, ch = q - r * CO_CPR;
+      int c32 = (ch >> 1) ^ tr_swz(r, RBO / 32);
+      *(uint4*)(ob + r * RBO + c32 * 32 + (ch & 1) * 16) = oreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < ICH; ++i) {
+      int q = tid + 256 * i;
+      int r = q / CI_CPR, ch = q - r * CI_CPR;
+      int c32 = (ch >> 1) ^ tr_swz(r, RBI / 32);
+      *(uint4*)(ib + r * RBI + c32 * 32 + (ch & 1) * 16) = ireg[i];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    load_global(0);
+    write_lds(0);
+  }
+  __syncthreads();
+
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk) load_global(ks + 1);
+    const unsigned char* ob = smem + buf * STAGE;
+    const unsigned char* ib = ob + 64 * RBO;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int r0 = kk * 32 + 8 * g + qq;  // pixel row this lane addresses (first half)
+      bf16x8 of[MT], xf[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        int c32 = wc * MT + m;  // 16-channel group == one 32-byte chunk
+        s16x4 lo = ds_read_tr16(ob + r0 * RBO + ((c32 ^ tr_swz(r0, RBO / 32)) * 32) + pp * 8);
+        s16x4 hi = ds_read_tr16(ob + (r0 + 4) * RBO + ((c32 ^ tr_swz(r0 + 4, RBO / 32)) * 32) + pp * 8);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        of[m] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        int c32 = wi * NT + n;
+        s16x4 lo = ds_read_tr16(ib + r0 * RBI + ((c32 ^ tr_swz(r0, RBI / 32)) * 32) + pp * 8);
+        s16x4 hi = ds_read_tr16(ib + (r0 + 4) * RBI + ((c32 ^ tr_swz(r0 + 4, RBI / 32)) * 32) + pp * 8);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        xf[n] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of[m], xf[n], acc[m][n], 0, 0, 0);
+    }
+    if (ks + 1 < nk) write_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: [co][ci] fp32 tile through LDS, then 256-byte-contiguous atomics
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int col = (wc * MT + m) * 16 + fq * 4 + r;
+        int cil = (wi * NT + n) * 16 + fr;
+        *(float*)(smem + col * EROW + cil * 4) = acc[m][n][r];
+      }
+  __syncthreads();
+  for (int q = tid; q < BCO * BCI; q += 256) {
+    int col = q / BCI, cil = q - col * BCI;
+    int co = co0 + col, ci = ci0 + cil;
+    if (co < a.Co && ci < a.Ci) {
+      float v = *(const float*)(smem + col * EROW + cil * 4);
+      atomicAdd(a.dw + ((long long)co * a.ntaps + tap) * a.Ci + ci, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem: 3x3, 3 -> 32, fp32 image in, bf16 out.  HBM-bound (writes 64 B per pixel); direct VALU.
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                       bf16_t* __restrict__ y, float* stats, int reps, int N, int H,
+                                                       int W) {
+  __shared__ float ws[32 * 27];
+  __shared__ float red[2][32];
+  for (int i = threadIdx.x; i < 32 * 27; i += 256) ws[i] = w[i];
+  if (threadIdx.x < 64) red[threadIdx.x >> 5][threadIdx.x & 31] = 0.f;
+  __syncthreads();
+  // 256 threads = 64 pixels x 4 channel-octets
+  const int oct = threadIdx.x & 3;
+  const long long P = (long long)N * H * W;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  for (long long p = (long long)blockIdx.x * 64 + (threadIdx.x >> 2); p < P; p += (long long)gridDim.x * 64) {
+    int wx = (int)(p % W);
+    long long t = p / W;
+    int hy = (int)(t % H);
+    int n = (int)(t / H);
+    float in[27];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        int hh = hy + kh - 1, ww = wx + kw - 1;
+        bool v = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+        const float* q = img + (((long long)n * H + hh) * W + ww) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) in[(kh * 3 + kw) * 3 + c] = v ? q[c] : 0.f;
+      }
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* wr = ws + (oct * 8 + j) * 27;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) acc = fmaf(in[k], wr[k], acc);
+      o[j] = acc;
+    }
+    uint4 pk = pack8(o);
+    *(uint4*)(y + p * 32 + oct * 8) = pk;
+    float r[8];
+    unpack8(pk, r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] += r[j]; s2[j] += r[j] * r[j]; }
+  }
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // lanes with equal (lane & 3) hold the same channel octet
+      float a = s1[j], b = s2[j];
+#pragma unroll
+      for (int o = 32; o >= 4; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+      if ((threadIdx.x & 63) < 4) {
+        atomicAdd(&red[0][oct * 8 + j], a);
+        atomicAdd(&red[1][oct * 8 + j], b);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      int rep = blockIdx.x % reps;
+      atomicAdd(stats + ((long long)rep * 2 + (threadIdx.x >> 5)) * 32 + (threadIdx.x & 31),
+                red[threadIdx.x >> 5][threadIdx.x & 31]);
+    }
+  }
+}
+
+// dW[co][tap][c] = sum_p dy[p][co] * img[p (+) tap][c] ; 864 outputs reduced over all pixels.
+// thread = (channel co = tid & 31, pixel lane = tid >> 5): 27 private accumulators.
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy,
+                                                         float* dw, int N, int H, int W) {
+  __shared__ float red[32 * 27];
+  for (int i = threadIdx.x; i < 32 * 27; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int co = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const long long P = (long long)N * H * W;
+  float acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+  for (long long p = (long long)blockIdx.x * 8 + pl; p < P; p += (long long)gridDim.x * 8) {
+    int wx = (int)(p % W);
+    long long t = p / W;
+    int hy = (int)(t % H);
+    int n = (int)(t / H);
+    float g = bf2f(dy[p * 32 + co]);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        int hh = hy + kh - 1, ww = wx + kw - 1;
+        if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) {
+          const float* q = img + (((long long)n * H + hh) * W + ww) * 3;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc[(kh * 3 + kw) * 3 + c] = fmaf(g, q[c], acc[(kh * 3 + kw) * 3 + c]);
+        }
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) atomicAdd(&red[co * 27 + k], acc[k]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * 27; i += 256) atomicAdd(dw + i, red[i]);
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Co, int T, int Ci,
+                                    int transpose, int ntaps_out, unsigned long long srccode, int rows_pad,
+                                    int K_pad) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long tot = (long long)rows_pad * K_pad;
+  if (i >= tot) return;
+  int r = (int)(i / K_pad), k = (int)(i - (long long)r * K_pad);
+  int rows = transpose ? Ci : Co, cin = transpose ? Co : Ci;
+  float v = 0.f;
+  if (r < rows && k < ntaps_out * cin) {
+    int t = k / cin, c = k - t * cin;
+    int st = (int)((srccode >> (4 * t)) & 15);
+    v = transpose ? w[((long long)c * T + st) * Ci + r] : w[((long long)r * T + st) * Ci + c];
+  }
+  out[i] = f2bf(v);
+}
+
+unsigned long long make_tapcode(int ntaps, const int32_t* dh, const int32_t* dw, bool* ok) {
+  unsigned long long code = 0;
+  *ok = true;
+  for (int t = 0; t < ntaps; ++t) {
+    if (dh[t] < -1 || dh[t] > 1 || dw[t] < -1 || dw[t] > 1) *ok = false;
+    code |= (unsigned long long)(((dh[t] + 1) & 3) | (((dw[t] + 1) & 3) << 2)) << (4 * t);
+  }
+  return code;
+}
+
+template <int WC, int WP, int MT, int NT>
+int launch_gemm(GemmArgs& a, hipStream_t st) {
+  constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
+  a.tilesC = a.Co_pad / BNC;
+  int tilesP = cdiv(a.M, BMP);
+  a.nblk = a.tilesC * tilesP;
+  size_t stage = (size_t)(BNC + BMP) * ROWB * 2;
+  size_t epi = (size_t)BMP * (BNC * (a.dst_f32 ? 4 : 2) + 16);
+  size_t lds = stage > epi ? stage : epi;
+  auto k = conv_gather_gemm_kernel<WC, WP, MT, NT>;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), lds, st, a);
+  return 0;
+}
+
+template <int WC, int WI, int MT, int NT>
+int launch_wgrad(WgradArgs& a, hipStream_t st) {
+  constexpr int BCO = WC * MT * 16, BCI = WI * NT * 16;
+  a.tilesCo = cdiv(a.Co, BCO);
+  a.tilesCi = cdiv(a.Ci, BCI);
+  size_t stage = (size_t)64 * (BCO + BCI) * 2 * 2;
+  size_t epi = (size_t)BCO * (BCI + 4) * 4;
+  size_t lds = stage > epi ? stage : epi;
+  auto k = conv_wgrad_kernel<WC, WI, MT, NT>;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    attr = true;
+  }
+  int nblk = a.tilesCo * a.tilesCi * a.ntaps * a.splits;
+  hipLaunchKernelGGL(k, dim3(nblk), dim3(256), lds, st, a);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
+  MGD_REQUIRE(d && d->src && d->wpk && d->dst, "conv: null pointer");
+  MGD_REQUIRE(d->Ci % 8 == 0 && d->Ci >= 8, "conv: Ci=%d must be a multiple of 8", d->Ci);
+  MGD_REQUIRE(d->Co % 8 == 0, "conv: Co=%d must be a multiple of 8", d->Co);
+  MGD_REQUIRE(d->ntaps >= 1 && d->ntaps <= 9, "conv: ntaps=%d", d->ntaps);
+  MGD_REQUIRE(d->K_pad % BK == 0 && d->K_pad >= d->ntaps * d->Ci, "conv: K_pad=%d too small/unaligned", d->K_pad);
+  MGD_REQUIRE(d->Co_pad >= d->Co && d->Co_pad % 32 == 0, "conv: Co_pad=%d", d->Co_pad);
+  MGD_REQUIRE(!(d->stats && d->dst_f32), "conv: stats epilogue needs bf16 output");
+  MGD_REQUIRE(!d->stats || d->stats_replicas >= 1, "conv: stats_replicas");
+  MGD_REQUIRE((d->Hg - 1) * d->out_stride + d->out_off_h < d->Hd && (d->Wg - 1) * d->out_stride + d->out_off_w < d->Wd,
+              "conv: iteration grid exceeds destination");
+  MGD_REQUIRE((long long)d->N * d->Hg * d->Wg < (1ll << 31), "conv: too many pixels");
+  bool ok;
+  GemmArgs a;
+  a.src = (const bf16_t*)d->src; a.wpk = (const bf16_t*)d->wpk; a.dst = d->dst; a.bias = d->bias;
+  a.addend = (const bf16_t*)d->addend; a.stats = d->stats;
+  a.N = d->N; a.Hs = d->Hs; a.Ws = d->Ws; a.Ci = d->Ci; a.Hg = d->Hg; a.Wg = d->Wg; a.Hd = d->Hd; a.Wd = d->Wd;
+  a.Co = d->Co; a.in_stride = d->in_stride; a.out_stride = d->out_stride; a.out_off_h = d->out_off_h;
+  a.out_off_w = d->out_off_w; a.ntaps = d->ntaps;
+  a.tapcode = make_tapcode(d->ntaps, d->dh, d->dw, &ok);
+  MGD_REQUIRE(ok, "conv: tap offsets must lie in [-1,1]");
+  a.K_pad = d->K_pad; a.Co_pad = d->Co_pad; a.dst_f32 = d->dst_f32; a.stats_replicas = d->stats_replicas;
+  a.M = d->N * d->Hg * d->Wg;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->Co_pad % 128 == 0) launch_gemm<2, 2, 4, 4>(a, st);
+  else if (d->Co_pad % 64 == 0) launch_gemm<1, 4, 4, 2>(a, st);
+  else launch_gemm<1, 4, 2, 2>(a, st);
+  MGD_CHECK_LAUNCH("conv_gather_gemm");
+  return MGD_OK;
+}
+
+extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
+  MGD_REQUIRE(d && d->src && d->dy && d->dw, "wgrad: null pointer");
+  MGD_REQUIRE(d->Ci % 8 == 0 && d->Co % 8 == 0, "wgrad: channels must be multiples of 8");
+  MGD_REQUIRE(d->ntaps >= 1 && d->ntaps <= 9 && d->splits >= 1, "wgrad: ntaps/splits");
+  MGD_REQUIRE((long long)d->N * d->Hg * d->Wg < (1ll << 31), "wgrad: too many pixels");
+  bool ok;
+  WgradArgs a;
+  a.src = (const bf16_t*)d->src; a.dy = (const bf16_t*)d->dy; a.dw = d->dw;
+  a.N = d->N; a.Hs = d->Hs; a.Ws = d->Ws; a.Ci = d->Ci; a.Hg = d->Hg; a.Wg = d->Wg; a.Co = d->Co;
+  a.in_stride = d->in_stride; a.ntaps = d->ntaps;
+  a.tapcode = make_tapcode(d->ntaps, d->dh, d->dw_off, &ok);
+  MGD_REQUIRE(ok, "wgrad: tap offsets must lie in [-1,1]");
+  a.P = d->N * d->Hg * d->Wg;
+  a.splits = d->splits;
+  a.chunk = ((cdiv(a.P, a.splits) + 63) / 64) * 64;
+  a.splits = cdiv(a.P, a.chunk);
+  a.rcp_hw = 1.0f / (float)(d->Hg * d->Wg);
+  a.rcp_w = 1.0f / (float)d->Wg;
+  hipStream_t st = (hipStream_t)stream;
+  int co = d->Co, ci = d->Ci;
+  if (co > 64 && ci > 64) launch_wgrad<2, 2, 4, 4>(a, st);
+  else if (co > 32 && ci > 32) launch_wgrad<2, 2, 2, 2>(a, st);
+  else if (ci <= 32) launch_wgrad<2, 2, 2, 1>(a, st);
+  else launch_wgrad<2, 2, 1, 2>(a, st);
+  MGD_CHECK_LAUNCH("conv_wgrad");
+  return MGD_OK;
+}
+
+extern "C" int mgd_stem_fwd(const float* image, const float* w, void* y, float* stats, int stats_replicas, int N,
+                            int H, int W, void* stream) {
+  MGD_REQUIRE(image && w && y, "stem_fwd: null pointer");
+  MGD_REQUIRE(!stats || stats_replicas >= 1, "stem_fwd: stats_replicas");
+  long long P = (long long)N * H * W;
+  int grid = (int)((P + 63) / 64);
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, image, w, (bf16_t*)y, stats,
+                     stats_replicas > 0 ? stats_replicas : 1, N, H, W);
+  MGD_CHECK_LAUNCH("stem_fwd");
+  return MGD_OK;
+}
+
+extern "C" int mgd_stem_wgrad(const float* image, const void* dy, float* dw, int N, int H, int W, void* stream) {
+  MGD_REQUIRE(image && dy && dw, "stem_wgrad: null pointer");
+  long long P = (long long)N * H * W;
+  int grid = (int)((P + 7) / 8);
+  if (grid > 256 * 8) grid = 256 * 8;
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, image, (const bf16_t*)dy, dw,
+                     N, H, W);
+  MGD_CHECK_LAUNCH("stem_wgrad");
+  return MGD_OK;
+}
+
+extern "C" int mgd_pack_weights(const float* w, void* out, int Co, int T, int Ci, int transpose, int ntaps_out,
+                                const int32_t* src_tap_host, int rows_pad, int K_pad, void* stream) {
+  MGD_REQUIRE(w && out && src_tap_host, "pack: null pointer");
+  MGD_REQUIRE(ntaps_out >= 1 && ntaps_out <= 9 && T <= 9, "pack: taps");
+  unsigned long long code = 0;
+  for (int t = 0; t < ntaps_out; ++t) {
+    MGD_REQUIRE(src_tap_host[t] >= 0 && src_tap_host[t] < T, "pack: src_tap out of range");
+    code |= (unsigned long long)src_tap_host[t] << (4 * t);
+  }
+  int rows = transpose ? Ci : Co, cin = transpose ? Co : Ci;
+  MGD_REQUIRE(rows_pad >= rows && K_pad >= ntaps_out * cin, "pack: padded sizes too small");
+  long long tot = (long long)rows_pad * K_pad;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)out,
+                     Co, T, Ci, transpose, ntaps_out, code, rows_pad, K_pad);
+  MGD_CHECK_LAUNCH("pack_weights");
+  return MGD_OK;
+}

@@ -1,0 +1,455 @@
+// MultiGridLoss forward + backward on gfx950, one wavefront per grid cell.
+// Replaces MultiGridLoss.compute_loss and helpers (reference multigriddet/losses/multigrid_loss.py:233-443,
+// 445-492 IoU, 494-703 ignore mask, 729-757 MSE, 759-799 anchor BCE, 829-859 class BCE, 861-928
+// objectness, 930-1043 variance consensus; losses/focal_loss.py:40-77 sigmoid focal).
+//
+// HBM-bound: algorithmic bytes = read y_pred + y_true (2 x B*cells*F*4) + write the gradient.
+// A cell's F = 5+A+C channels sit on the 64 lanes (coalesced 256-byte loads), the per-image list of
+// ground-truth boxes (= every positive cell, as in the reference) is staged once per block in LDS,
+// and the ignore-mask IoU search runs lanes-over-GT with a wave max.  All reference quirks are kept:
+// the transposed 'ij' grid (:545-551), pixel anchors multiplied by the stride again (:572),
+// anchor_scale and object_scale applied twice (:349/:433, :908/:432).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXL = 4, MAXA = 8;
+constexpr int CELLS_PER_BLOCK = 64;
+constexpr int GT_LDS = 1024;
+constexpr float KEPS = 1e-7f;
+
+struct LossArgs {
+  mgd_loss_cfg cfg;
+  const float* yp[MAXL];
+  const float* yt[MAXL];
+  float* gf[MAXL];       // f32 gradient (may be null)
+  bf16_t* gb[MAXL];      // bf16 gradient (may be null)
+  const float* class_w;  // may be null
+  int* gt_count;         // [L][B]
+  int* npos;             // [L]
+  int* ncenter;          // [L]
+  float4* gt;            // [sum_l B*g*g]
+  float* assigned;       // [sum_l B*g*g]
+  double* acc;           // [8]
+  long long cell_off[MAXL + 1];
+  float* components;
+};
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float bce_logits(float z, float x) {
+  return fmaxf(x, 0.f) - x * z + log1pf(__expf(-fabsf(x)));
+}
+__device__ __forceinline__ float xy_act(float p) { return tanhf(0.15f * p) + sigmoidf(0.15f * p); }
+__device__ __forceinline__ float xy_act_grad(float p) {
+  float t = tanhf(0.15f * p), s = sigmoidf(0.15f * p);
+  return 0.15f * (1.f - t * t) + 0.15f * s * (1.f - s);
+}
+
+__device__ __forceinline__ float norm_factor(const mgd_loss_cfg& c, int l, int npos) {
+  float f = 1.f;
+  float B = (float)c.B;
+  for (int i = 0; i < c.norm_positives; ++i) f *= fmaxf((float)npos, 1.f);
+  for (int i = 0; i < c.norm_batch; ++i) f *= B;
+  for (int i = 0; i < c.norm_grid; ++i) f *= B * (float)c.grid_h[l] * (float)c.grid_w[l];
+  return fmaxf(f, 1.f);
+}
+
+// ---- K1: collect the per-image GT list (every positive cell) and the counters
+__global__ void loss_prep_kernel(LossArgs a, int l) {
+  const mgd_loss_cfg& c = a.cfg;
+  const int gh = c.grid_h[l], gw = c.grid_w[l], F = 5 + c.A + c.C;
+  long long ncell = (long long)c.B * gh * gw;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncell) return;
+  const float* t = a.yt[l] + i * F;
+  a.assigned[a.cell_off[l] + i] = 0.f;
+  if (!(t[4] > 0.5f)) return;
+  int b = (int)(i / (gh * gw));
+  int rem = (int)(i - (long long)b * gh * gw);
+  int row = rem / gw, col = rem - row * gw;
+  float sx = (float)c.in_w / (float)gw, sy = (float)c.in_h / (float)gh;
+  // transposed grid: x gets the row index, y the column index (reference :545-551)
+  float gx = (t[0] + (float)row) * sx, gy = (t[1] + (float)col) * sy;
+  int k = 0;
+  float best = t[5];
+  for (int j = 1; j < c.A; ++j)
+    if (t[5 + j] > best) { best = t[5 + j]; k = j; }
+  float w = __expf(t[2]) * c.anchors[l][k][0] * sx, h = __expf(t[3]) * c.anchors[l][k][1] * sy;
+  int slot = atomicAdd(a.gt_count + l * c.B + b, 1);
+  a.gt[a.cell_off[l] + (long long)b * gh * gw + slot] = make_float4(gx, gy, w, h);
+  atomicAdd(a.npos + l, 1);
+  if (t[0] >= 0.f && t[0] < 1.f && t[1] >= 0.f && t[1] < 1.f) atomicAdd(a.ncenter + l, 1);
+}
+
+// ---- K2: per-cell loss and gradient.  grid = (cells chunks, B, 1) per scale.
+__global__ __launch_bounds__(256) void loss_cell_kernel(LossArgs a, int l) {
+  const mgd_loss_cfg& c = a.cfg;
+  const int gh = c.grid_h[l], gw = c.grid_w[l], A = c.A, C = c.C, F = 5 + A + C;
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float4 gts[GT_LDS];
+  __shared__ float wsum[4][4];
+
+  const int ngt = a.gt_count[l * c.B + b];
+  const float4* gtg = a.gt + a.cell_off[l] + (long long)b * gh * gw;
+  const bool in_lds = ngt <= GT_LDS;
+  if (in_lds)
+    for (int i = threadIdx.x; i < ngt; i += 256) gts[i] = gtg[i];
+  __syncthreads();
+
+  const float nf = norm_factor(c, l, a.npos[l]);
+  const float inv_nf = 1.0f / nf;
+  const float sx = (float)c.in_w / (float)gw, sy = (float)c.in_h / (float)gh;
+  const float gscale = c.grad_out_scale;
+
+  float s_loc = 0.f, s_obj = 0.f, s_anc = 0.f, s_cls = 0.f;
+  const int cell_beg = blockIdx.x * CELLS_PER_BLOCK;
+  const int cell_end = min(gh * gw, cell_beg + CELLS_PER_BLOCK);
+  for (int cell = cell_beg + wave; cell < cell_end; cell += 4) {
+    const long long gcell = (long long)b * gh * gw + cell;
+    const float* p = a.yp[l] + gcell * F;
+    const float* t = a.yt[l] + gcell * F;
+    const int row = cell / gw, col = cell - row * gw;
+    // channel ch0 = lane, ch1 = 64 + lane
+    const int ch0 = lane, ch1 = 64 + lane;
+    float p0 = ch0 < F ? p[ch0] : 0.f, t0 = ch0 < F ? t[ch0] : 0.f;
+    float p1 = ch1 < F ? p[ch1] : 0.f, t1 = ch1 < F ? t[ch1] : 0.f;
+    // broadcast the header channels
+    float pxr = __shfl(p0, 0, 64), pyr = __shfl(p0, 1, 64), pwr = __shfl(p0, 2, 64), phr = __shfl(p0, 3, 64);
+    float tob = __shfl(t0, 4, 64);
+    const float obj = tob > 0.5f ? 1.f : 0.f;
+    // predicted boxes (absolute), transposed grid as in the reference
+    float ax = xy_act(pxr), ay = xy_act(pyr);
+    float bx = (ax + (float)row) * sx, by = (ay + (float)col) * sy;
+    float ew = __expf(pwr), eh = __expf(phr);
+    float iou_a[MAXA];
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j) iou_a[j] = 0.f;
+    for (int g0 = 0; g0 < ngt; g0 += 64) {
+      int g = g0 + lane;
+      if (g < ngt) {
+        float4 G = in_lds ? gts[g] : gtg[g];
+        float gx0 = G.x - G.z / 2.0f, gx1 = G.x + G.z / 2.0f, gy0 = G.y - G.w / 2.0f, gy1 = G.y + G.w / 2.0f;
+        float garea = G.z * G.w;
+#pragma unroll
+        for (int j = 0; j < MAXA; ++j) {
+          if (j < A) {
+            float w = ew * c.anchors[l][j][0] * sx, h = eh * c.anchors[l][j][1] * sy;
+            float iw = fmaxf(fminf(bx + w / 2.0f, gx1) - fmaxf(bx - w / 2.0f, gx0), 0.f);
+            float ih = fmaxf(fminf(by + h / 2.0f, gy1) - fmaxf(by - h / 2.0f, gy0), 0.f);
+            float inter = iw * ih;
+            float iou = inter / (w * h + garea - inter + KEPS);
+            iou_a[j] = fmaxf(iou_a[j], iou);
+          }
+        }
+      }
+    }
+    float max_iou = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j)
+      if (j < A) {
+        iou_a[j] = wave_max(iou_a[j]);
+        max_iou = j == 0 ? iou_a[0] : fmaxf(max_iou, iou_a[j]);
+      }
+    const float ignore = (max_iou > c.ignore_thresh && tob < 0.5f) ? 1.f : 0.f;
+    // assigned-anchor IoU (argmax of the true anchor one-hot, first max)
+    int kstar = 0;
+    {
+      float best = __shfl(t0, 5, 64);
+      for (int j = 1; j < A; ++j) {
+        float v = __shfl(t0, 5 + j, 64);
+        if (v > best) { best = v; kstar = j; }
+      }
+    }
+    float assigned = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j)
+      if (j == kstar) assigned = iou_a[j];
+    assigned *= obj;
+    if (lane == 0) a.assigned[a.cell_off[l] + gcell] = assigned;
+
+    // objectness target / weight
+    float tgt = tob;
+    if (c.use_iou_aware_objectness) {
+      float piou = fminf(fmaxf(assigned, 0.f), 1.f);
+      float blended = c.iou_objectness_ratio * powf(piou + KEPS, c.iou_objectness_power) +
+                      (1.f - c.iou_objectness_ratio) * tob;
+      tgt = obj * blended + (1.f - obj) * tgt;
+    }
+    float wobj = obj * c.object_scale + (1.f - obj) * (1.f - ignore) * c.no_object_scale;
+    if (c.trainable_nms_weight > 0.f)
+      wobj += (1.f - obj) * ignore * c.trainable_nms_weight *
+              powf(fminf(fmaxf(max_iou, 0.f), 1.f) + KEPS, c.trainable_nms_power);
+
+    // per-channel loss / gradient
+    float g0v = 0.f, g1v = 0.f;
+    auto channel = [&](int ch, float pv, float tv, float& gout) {
+      gout = 0.f;
+      if (ch >= F) return;
+      if (ch < 2) {
+        float act = xy_act(pv);
+        float d = act - tv;
+        s_loc += obj * d * d;
+        gout = c.coord_scale * obj * 2.f * d * xy_act_grad(pv) * inv_nf;
+      } else if (ch < 4) {
+        float d = pv - tv;
+        s_loc += obj * d * d;
+        gout = c.coord_scale * obj * 2.f * d * inv_nf;
+      } else if (ch == 4) {
+        s_obj += bce_logits(tgt, pv) * wobj;
+        gout = c.object_scale * wobj * (sigmoidf(pv) - tgt) * inv_nf;
+      } else if (ch < 5 + A) {
+        float m = obj * (1.f - ignore);
+        s_anc += bce_logits(tv, pv) * m;
+        gout = c.anchor_scale * c.anchor_scale * m * (sigmoidf(pv) - tv) * inv_nf;
+      } else {
+        float cw = a.class_w ? a.class_w[ch - 5 - A] : 1.f;
+        if (c.use_focal_loss) {
+          float pr = sigmoidf(pv);
+          float pt = tv * pr + (1.f - tv) * (1.f - pr);
+          float om = fmaxf(1.f - pt, 0.f);
+          float mod = powf(om, c.focal_gamma);
+          float at = tv * c.focal_alpha + (1.f - tv) * (1.f - c.focal_alpha);
+          float bce = bce_logits(tv, pv);
+          s_cls += mod * at * bce * cw * obj;
+          float dmod = om > 0.f ? -c.focal_gamma * powf(om, c.focal_gamma - 1.f) * (2.f * tv - 1.f) * pr * (1.f - pr) : 0.f;
+          gout = c.class_scale * cw * obj * at * (dmod * bce + mod * (pr - tv)) * inv_nf;
+        } else {
+          float ts = c.label_smoothing > 0.f ? tv * (1.f - c.label_smoothing) + c.label_smoothing / (float)C : tv;
+          s_cls += bce_logits(ts, pv) * cw * obj;
+          gout = c.class_scale * cw * obj * (sigmoidf(pv) - ts) * inv_nf;
+        }
+      }
+    };
+    channel(ch0, p0, t0, g0v);
+    channel(ch1, p1, t1, g1v);
+    g0v *= gscale;
+    g1v *= gscale;
+    if (a.gf[l]) {
+      float* g = a.gf[l] + gcell * F;
+      if (ch0 < F) g[ch0] = g0v;
+      if (ch1 < F) g[ch1] = g1v;
+    }
+    if (a.gb[l]) {
+      bf16_t* g = a.gb[l] + gcell * F;
+      if (ch0 < F) g[ch0] = f2bf(g0v);
+      if (ch1 < F) g[ch1] = f2bf(g1v);
+    }
+  }
+  s_loc = wave_sum(s_loc); s_obj = wave_sum(s_obj); s_anc = wave_sum(s_anc); s_cls = wave_sum(s_cls);
+  if (lane == 0) { wsum[wave][0] = s_loc; wsum[wave][1] = s_obj; wsum[wave][2] = s_anc; wsum[wave][3] = s_cls; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float v = wsum[0][threadIdx.x] + wsum[1][threadIdx.x] + wsum[2][threadIdx.x] + wsum[3][threadIdx.x];
+    v *= inv_nf;
+    if (threadIdx.x == 2) v *= c.anchor_scale;   // reference accumulates anchor_scale * anchor_loss (:349,:390)
+    atomicAdd(a.acc + threadIdx.x, (double)v);
+  }
+}
+
+// ---- K3: variance consensus (reference :930-1043), kernel size 3.  One wave per centre cell.
+__global__ __launch_bounds__(256) void loss_consensus_kernel(LossArgs a, int l) {
+  const mgd_loss_cfg& c = a.cfg;
+  const int gh = c.grid_h[l], gw = c.grid_w[l], A = c.A, C = c.C, F = 5 + A + C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long ncell = (long long)c.B * gh * gw;
+  const long long gcell = (long long)blockIdx.x * 4 + wave;
+  if (gcell >= ncell) return;
+  const float* t = a.yt[l] + gcell * F;
+  float t0 = t[0], t1 = t[1], tob = t[4];
+  if (!(tob > 0.5f && t0 >= 0.f && t0 < 1.f && t1 >= 0.f && t1 < 1.f)) return;
+  const int b = (int)(gcell / (gh * gw));
+  const int cell = (int)(gcell - (long long)b * gh * gw);
+  const int row = cell / gw, col = cell - row * gw;
+  const float cx0 = t0 + (float)row, cy0 = t1 + (float)col;   // transposed grid again (:937)
+  // weights over the 3x3 patch (computed redundantly by every lane)
+  float w[9];
+  long long nb[9];
+  float wsumv = 0.f;
+#pragma unroll
+  for (int p = 0; p < 9; ++p) {
+    int rr = row + p / 3 - 1, cc = col + p % 3 - 1;
+    w[p] = 0.f;
+    nb[p] = -1;
+    if (rr < 0 || rr >= gh || cc < 0 || cc >= gw) continue;
+    long long n = (long long)b * gh * gw + rr * gw + cc;
+    nb[p] = n;
+    const float* tn = a.yt[l] + n * F;
+    float m = tn[4] > 0.5f ? 1.f : 0.f;
+    float dx = fabsf(tn[0] + (float)rr - cx0), dy = fabsf(tn[1] + (float)cc - cy0);
+    float same = fmaxf(dx, dy) < c.consensus_center_tolerance ? 1.f : 0.f;
+    float gm = m * same;
+    if (gm > 0.f) {
+      float iou = fmaxf(a.assigned[a.cell_off[l] + n], c.consensus_min_iou);
+      w[p] = powf(iou, c.consensus_iou_power) * gm;
+    }
+    wsumv += w[p];
+  }
+  float inv = 1.0f / (wsumv + KEPS);
+#pragma unroll
+  for (int p = 0; p < 9; ++p) w[p] *= inv;
+  float wtot = 0.f;
+#pragma unroll
+  for (int p = 0; p < 9; ++p) wtot += w[p];
+  const float normalizer = fmaxf((float)a.ncenter[l], 1.f);
+  float s_coord = 0.f, s_objv = 0.f, s_clsv = 0.f;
+  for (int ch = lane; ch < F; ch += 64) {
+    if (ch >= 5 && ch < 5 + A) continue;      // anchor logits take no part
+    const bool is_box = ch < 4, is_obj = ch == 4;
+    float v[9], dv[9];
+    float cons = 0.f;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      float raw = nb[p] >= 0 ? a.yp[l][nb[p] * F + ch] : 0.f;
+      if (is_box) { v[p] = nb[p] >= 0 ? raw : 0.f; dv[p] = 1.f; }
+      else {
+        float s = sigmoidf(raw);
+        v[p] = nb[p] >= 0 ? s : 0.f;           // zero-padded patch of probabilities
+        dv[p] = s * (1.f - s);
+      }
+      cons += w[p] * v[p];
+    }
+    float var = 0.f, lin = 0.f;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      float d = v[p] - cons;
+      var += w[p] * d * d;
+      lin += w[p] * d;
+    }
+    float coef = is_box ? c.consensus_coord_scale / normalizer
+                        : (is_obj ? c.consensus_obj_scale / normalizer
+                                  : c.consensus_class_scale / (normalizer * (float)C));
+    if (is_box) s_coord += var; else if (is_obj) s_objv += var; else s_clsv += var;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      if (nb[p] < 0 || w[p] == 0.f) continue;
+      float d = v[p] - cons;
+      float g = 2.f * w[p] * d;
+      if (!c.consensus_stop_gradient) g -= 2.f * w[p] * lin * wtot;   // d cons / d v_p = w_p
+      g *= dv[p] * coef * c.grad_out_scale;
+      atomicAdd(a.gf[l] + nb[p] * F + ch, g);
+    }
+  }
+  s_coord = wave_sum(s_coord); s_objv = wave_sum(s_objv); s_clsv = wave_sum(s_clsv);
+  if (lane == 0) {
+    atomicAdd(a.acc + 4, (double)(s_coord / normalizer));
+    atomicAdd(a.acc + 5, (double)(s_objv / normalizer));
+    atomicAdd(a.acc + 6, (double)(s_clsv / (normalizer * (float)C)));
+  }
+}
+
+__global__ void loss_finalize_kernel(LossArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const mgd_loss_cfg& c = a.cfg;
+  float v[8];
+  for (int i = 0; i < 7; ++i) v[i] = (float)a.acc[i];
+  float tot = c.coord_scale * v[0] + c.object_scale * v[1] + c.anchor_scale * v[2] + c.class_scale * v[3];
+  if (c.use_consensus_loss)
+    tot += c.consensus_coord_scale * v[4] + c.consensus_obj_scale * v[5] + c.consensus_class_scale * v[6];
+  v[7] = tot;
+  for (int i = 0; i < 8; ++i) a.components[i] = v[i];
+}
+
+struct WsLayout {
+  size_t gt_count, npos, ncenter, acc, gt, assigned, gscratch, total;
+  long long cell_off[MAXL + 1];
+};
+
+WsLayout ws_layout(const mgd_loss_cfg* c) {
+  WsLayout w;
+  long long cells = 0;
+  for (int l = 0; l < c->L; ++l) {
+    w.cell_off[l] = cells;
+    cells += (long long)c->B * c->grid_h[l] * c->grid_w[l];
+  }
+  w.cell_off[c->L] = cells;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+  w.acc = take(8 * sizeof(double));
+  w.gt_count = take((size_t)c->L * c->B * 4);
+  w.npos = take(MAXL * 4);
+  w.ncenter = take(MAXL * 4);
+  size_t header = o;
+  (void)header;
+  w.gt = take((size_t)cells * 16);
+  w.assigned = take((size_t)cells * 4);
+  w.gscratch = take(c->use_consensus_loss ? (size_t)cells * (5 + c->A + c->C) * 4 : 0);
+  w.total = o;
+  return w;
+}
+
+}  // namespace
+
+extern "C" size_t mgd_loss_workspace_size(const mgd_loss_cfg* cfg) {
+  if (!cfg || cfg->L < 1 || cfg->L > MAXL) return 0;
+  return ws_layout(cfg).total;
+}
+
+extern "C" int mgd_loss_fwd_bwd(const mgd_loss_cfg* cfg, const float* const* y_pred_host,
+                                const float* const* y_true_host, const float* class_weights,
+                                float* const* grad_f32_host, void* const* grad_bf16_host, float* components,
+                                void* ws, size_t ws_bytes, void* stream) {
+  MGD_REQUIRE(cfg && y_pred_host && y_true_host && components && ws, "loss: null pointer");
+  MGD_REQUIRE(cfg->L >= 1 && cfg->L <= MAXL && cfg->A >= 1 && cfg->A <= MAXA, "loss: L=%d A=%d unsupported", cfg->L,
+              cfg->A);
+  MGD_REQUIRE(5 + cfg->A + cfg->C <= 128, "loss: 5+A+C=%d exceeds 128 channels", 5 + cfg->A + cfg->C);
+  MGD_REQUIRE(cfg->loss_option >= 1 && cfg->loss_option <= 3, "loss: loss_option=%d", cfg->loss_option);
+  MGD_REQUIRE(cfg->use_focal_loss == 0 || cfg->use_focal_loss == 1, "loss: use_focal_loss");
+  WsLayout w = ws_layout(cfg);
+  if (ws_bytes < w.total) return mgd_set_error(MGD_ENOSPC, "loss: workspace %zu < %zu", ws_bytes, w.total);
+  LossArgs a;
+  a.cfg = *cfg;
+  char* base = (char*)ws;
+  a.acc = (double*)(base + w.acc);
+  a.gt_count = (int*)(base + w.gt_count);
+  a.npos = (int*)(base + w.npos);
+  a.ncenter = (int*)(base + w.ncenter);
+  a.gt = (float4*)(base + w.gt);
+  a.assigned = (float*)(base + w.assigned);
+  a.class_w = class_weights;
+  a.components = components;
+  float* scratch = (float*)(base + w.gscratch);
+  bool scratch_used[MAXL] = {false, false, false, false};
+  for (int l = 0; l <= cfg->L; ++l) a.cell_off[l] = w.cell_off[l];
+  for (int l = 0; l < MAXL; ++l) { a.yp[l] = a.yt[l] = nullptr; a.gf[l] = nullptr; a.gb[l] = nullptr; }
+  const int F = 5 + cfg->A + cfg->C;
+  for (int l = 0; l < cfg->L; ++l) {
+    a.yp[l] = y_pred_host[l];
+    a.yt[l] = y_true_host[l];
+    MGD_REQUIRE(a.yp[l] && a.yt[l], "loss: y_pred/y_true[%d] null", l);
+    a.gf[l] = grad_f32_host ? grad_f32_host[l] : nullptr;
+    a.gb[l] = grad_bf16_host ? (bf16_t*)grad_bf16_host[l] : nullptr;
+    if (cfg->use_consensus_loss && !a.gf[l]) {   // consensus scatters into an f32 image
+      a.gf[l] = scratch + w.cell_off[l] * F;
+      scratch_used[l] = true;
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(base, 0, w.gt, st) != hipSuccess) return mgd_set_error(MGD_ELAUNCH, "loss: memset failed");
+  for (int l = 0; l < cfg->L; ++l) {
+    long long ncell = (long long)cfg->B * cfg->grid_h[l] * cfg->grid_w[l];
+    hipLaunchKernelGGL(loss_prep_kernel, dim3(cdiv(ncell, 256)), dim3(256), 0, st, a, l);
+  }
+  for (int l = 0; l < cfg->L; ++l) {
+    LossArgs al = a;
+    if (scratch_used[l]) al.gb[l] = nullptr;    // bf16 image is produced after the consensus scatter
+    int gx = cdiv(cfg->grid_h[l] * cfg->grid_w[l], CELLS_PER_BLOCK);
+    hipLaunchKernelGGL(loss_cell_kernel, dim3(gx, cfg->B), dim3(256), 0, st, al, l);
+  }
+  if (cfg->use_consensus_loss) {
+    for (int l = 0; l < cfg->L; ++l) {
+      if (!a.gf[l]) continue;
+      long long ncell = (long long)cfg->B * cfg->grid_h[l] * cfg->grid_w[l];
+      hipLaunchKernelGGL(loss_consensus_kernel, dim3(cdiv(ncell, 4)), dim3(256), 0, st, a, l);
+    }
+    for (int l = 0; l < cfg->L; ++l) {
+      if (!a.gb[l] || !a.gf[l]) continue;
+      long long n = (long long)cfg->B * cfg->grid_h[l] * cfg->grid_w[l] * F;
+      int rc = mgd_f32_to_bf16(a.gf[l], a.gb[l], n, stream);
+      if (rc != MGD_OK) return rc;
+    }
+  }
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, a);
+  MGD_CHECK_LAUNCH("loss_fwd_bwd");
+  return MGD_OK;
+}

@@ -1,0 +1,380 @@
+"""Thin tensor-level wrappers over the C-ABI (one Python function per entry point family).
+
+Everything here takes/returns torch CUDA tensors and enqueues on torch's current stream.  Layouts:
+activations NHWC bf16, master weights fp32 OHWI ([Co, kh*kw, Ci]), packed GEMM images bf16.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+BN_EPS = 1e-3          # Keras BatchNormalization default (reference models/layers.py:94)
+BN_MOMENTUM = 0.99
+LEAKY_SLOPE = 0.1
+STATS_REPLICAS = 16
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+def pad_cout(co):
+    for tile in (128, 64, 32):
+        p = _ru(co, tile)
+        if p / co - 1.0 <= 0.125:
+            return p
+    return _ru(co, 32)
+
+
+# ------------------------------------------------------------------------------------------- taps
+def taps_fwd(k):
+    if k == 1:
+        return [0], [0]
+    return [kh - 1 for kh in range(3) for _ in range(3)], [kw - 1 for _ in range(3) for kw in range(3)]
+
+
+def taps_dgrad_s2(ph, pw):
+    """Output-parity class (ph, pw) of the stride-2 transposed conv: (dh, dw, source tap)."""
+    out = []
+    for kh in ((1,) if ph == 0 else (0, 2)):
+        for kw in ((1,) if pw == 0 else (0, 2)):
+            out.append(((ph + 1 - kh) // 2, (pw + 1 - kw) // 2, kh * 3 + kw))
+    return out
+
+
+# ------------------------------------------------------------------------------------------- packing
+class PackedConv:
+    """Packed bf16 images of one conv's weights: forward + data-gradient variants."""
+
+    def __init__(self, co, ci, k, s, device, need_dgrad=True):
+        self.co, self.ci, self.k, self.s = co, ci, k, s
+        T = k * k
+        self.T = T
+        self.fwd_kpad = _ru(T * ci, 64)
+        self.fwd_copad = pad_cout(co)
+        self.fwd = torch.zeros(self.fwd_copad, self.fwd_kpad, dtype=torch.bfloat16, device=device)
+        self.dgrad = []
+        if need_dgrad:
+            if s == 1:
+                kp, cp = _ru(T * co, 64), pad_cout(ci)
+                self.dgrad.append((torch.zeros(cp, kp, dtype=torch.bfloat16, device=device), kp, cp,
+                                   [T - 1 - t for t in range(T)], None))
+            else:
+                for ph in range(2):
+                    for pw in range(2):
+                        tp = taps_dgrad_s2(ph, pw)
+                        kp, cp = _ru(len(tp) * co, 64), pad_cout(ci)
+                        self.dgrad.append((torch.zeros(cp, kp, dtype=torch.bfloat16, device=device), kp, cp,
+                                           [t[2] for t in tp], (ph, pw, tp)))
+
+    def refresh(self, w):
+        """w: fp32 [Co, T, Ci] master weights -> rewrite the packed images."""
+        lib = L.load()
+        src = (C.c_int32 * 9)(*range(self.T), *([0] * (9 - self.T)))
+        L.check(lib.mgd_pack_weights(L.ptr(w), L.ptr(self.fwd), self.co, self.T, self.ci, 0, self.T, src,
+                                     self.fwd_copad, self.fwd_kpad, L.stream_ptr()), "pack fwd")
+        for img, kp, cp, st, _ in self.dgrad:
+            src = (C.c_int32 * 9)(*st, *([0] * (9 - len(st))))
+            L.check(lib.mgd_pack_weights(L.ptr(w), L.ptr(img), self.co, self.T, self.ci, 1, len(st), src, cp, kp,
+                                         L.stream_ptr()), "pack dgrad")
+
+
+def _desc(src, wpk, dst, N, Hs, Ws, Ci, Hg, Wg, Hd, Wd, Co, in_stride, out_stride, off, dh, dw, K_pad, Co_pad,
+          bias=None, addend=None, stats=None, dst_f32=False):
+    d = L.ConvDesc()
+    d.src, d.wpk, d.dst = src.data_ptr(), wpk.data_ptr(), dst.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.addend = addend.data_ptr() if addend is not None else None
+    d.stats = stats.data_ptr() if stats is not None else None
+    d.N, d.Hs, d.Ws, d.Ci, d.Hg, d.Wg, d.Hd, d.Wd, d.Co = N, Hs, Ws, Ci, Hg, Wg, Hd, Wd, Co
+    d.in_stride, d.out_stride, d.out_off_h, d.out_off_w = in_stride, out_stride, off[0], off[1]
+    d.ntaps = len(dh)
+    for i, (a, b) in enumerate(zip(dh, dw)):
+        d.dh[i], d.dw[i] = a, b
+    d.K_pad, d.Co_pad, d.dst_f32 = K_pad, Co_pad, int(dst_f32)
+    d.stats_replicas = STATS_REPLICAS if stats is not None else 0
+    return d
+
+
+def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False):
+    """x: bf16 [N,H,W,Ci] -> [N,Ho,Wo,Co]; 'same' for stride 1, top/left pad + 'valid' for stride 2."""
+    N, H, W, Ci = x.shape
+    assert Ci == pk.ci and x.dtype == torch.bfloat16
+    Ho, Wo = (H // 2, W // 2) if pk.s == 2 else (H, W)
+    if out is None:
+        out = torch.empty(N, Ho, Wo, pk.co, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    dh, dw = taps_fwd(pk.k)
+    d = _desc(x, pk.fwd, out, N, H, W, Ci, Ho, Wo, Ho, Wo, pk.co, pk.s, 1, (0, 0), dh, dw, pk.fwd_kpad,
+              pk.fwd_copad, bias=bias, stats=stats, dst_f32=out_f32)
+    L.check(L.load().mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), "conv_fwd")
+    return out
+
+
+def conv_dgrad(dy, pk, in_hw, out=None, addend=None):
+    """dy: bf16 [N,Ho,Wo,Co] -> dx bf16 [N,H,W,Ci] (+ addend)."""
+    N, Ho, Wo, Co = dy.shape
+    H, W = in_hw
+    assert Co == pk.co and dy.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty(N, H, W, pk.ci, dtype=torch.bfloat16, device=dy.device)
+    lib = L.load()
+    if pk.s == 1:
+        img, kp, cp, _, _ = pk.dgrad[0]
+        dh, dw = taps_fwd(pk.k)
+        d = _desc(dy, img, out, N, Ho, Wo, Co, H, W, H, W, pk.ci, 1, 1, (0, 0), dh, dw, kp, cp, addend=addend)
+        L.check(lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), "conv_dgrad")
+    else:
+        for img, kp, cp, _, (ph, pw, tp) in pk.dgrad:
+            d = _desc(dy, img, out, N, Ho, Wo, Co, H // 2, W // 2, H, W, pk.ci, 1, 2, (ph, pw),
+                      [t[0] for t in tp], [t[1] for t in tp], kp, cp, addend=addend)
+            L.check(lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), "conv_dgrad_s2")
+    return out
+
+
+def wgrad_splits(P, co, ci, T, target_blocks=768):
+    bco = 128 if co > 64 else (64 if co > 32 else 32)
+    bci = 128 if ci > 64 else (64 if ci > 32 else 32)
+    base = -(-co // bco) * -(-ci // bci) * T
+    return max(1, min(target_blocks // base, -(-P // 256)))
+
+
+def conv_wgrad(x, dy, dw, k, s, splits=None):
+    """dw (fp32 [Co, k*k, Ci]) += x (*) dy."""
+    N, H, W, Ci = x.shape
+    _, Ho, Wo, Co = dy.shape
+    d = L.WgradDesc()
+    d.src, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+    d.N, d.Hs, d.Ws, d.Ci, d.Hg, d.Wg, d.Co = N, H, W, Ci, Ho, Wo, Co
+    d.in_stride = s
+    dh, dwo = taps_fwd(k)
+    d.ntaps = len(dh)
+    for i, (a, b) in enumerate(zip(dh, dwo)):
+        d.dh[i], d.dw_off[i] = a, b
+    d.splits = splits if splits is not None else wgrad_splits(N * Ho * Wo, Co, Ci, k * k)
+    L.check(L.load().mgd_conv_wgrad(C.byref(d), L.stream_ptr()), "conv_wgrad")
+    return dw
+
+
+def stem_fwd(image, w, out=None, stats=None):
+    N, H, W, _ = image.shape
+    if out is None:
+        out = torch.empty(N, H, W, 32, dtype=torch.bfloat16, device=image.device)
+    L.check(L.load().mgd_stem_fwd(L.ptr(image), L.ptr(w), L.ptr(out), L.ptr(stats),
+                                  STATS_REPLICAS if stats is not None else 0, N, H, W, L.stream_ptr()), "stem_fwd")
+    return out
+
+
+def stem_wgrad(image, dy, dw):
+    N, H, W, _ = image.shape
+    L.check(L.load().mgd_stem_wgrad(L.ptr(image), L.ptr(dy), L.ptr(dw), N, H, W, L.stream_ptr()), "stem_wgrad")
+    return dw
+
+
+# ------------------------------------------------------------------------------------------- BN / act
+def bn_finalize(stats, count, gamma, beta, mm, mv, scale, shift, smean, sinv, training=True):
+    Cn = gamma.numel()
+    L.check(L.load().mgd_bn_finalize(L.ptr(stats), STATS_REPLICAS, Cn, C.c_float(count), L.ptr(gamma), L.ptr(beta),
+                                     L.ptr(mm), L.ptr(mv), L.ptr(scale), L.ptr(shift), L.ptr(smean), L.ptr(sinv),
+                                     C.c_float(BN_EPS), C.c_float(BN_MOMENTUM), int(training), L.stream_ptr()),
+            "bn_finalize")
+
+
+def bn_act_fwd(y, scale, shift, out, residual=None):
+    Cn = y.shape[-1]
+    P = y.numel() // Cn
+    L.check(L.load().mgd_bn_act_fwd(L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(residual), L.ptr(out),
+                                    C.c_int64(P), Cn, C.c_float(LEAKY_SLOPE), L.stream_ptr()), "bn_act_fwd")
+    return out
+
+
+def bn_act_bwd(da, y, scale, shift, smean, sinv, sums, dgamma, dbeta, dy, frozen=False):
+    """sums: fp32 [(R+1)*2*C] zeroed scratch.  Writes dy, accumulates dgamma/dbeta."""
+    Cn = y.shape[-1]
+    P = y.numel() // Cn
+    lib = L.load()
+    if not frozen:
+        L.check(lib.mgd_bn_act_bwd_reduce(L.ptr(da), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(smean),
+                                          L.ptr(sinv), L.ptr(sums), STATS_REPLICAS, C.c_int64(P), Cn,
+                                          C.c_float(LEAKY_SLOPE), L.stream_ptr()), "bn_act_bwd_reduce")
+    L.check(lib.mgd_bn_act_bwd_apply(L.ptr(da), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(smean), L.ptr(sinv),
+                                     L.ptr(sums), STATS_REPLICAS, L.ptr(dgamma), L.ptr(dbeta), L.ptr(dy),
+                                     C.c_int64(P), Cn, C.c_float(LEAKY_SLOPE), int(frozen), L.stream_ptr()),
+            "bn_act_bwd_apply")
+    return dy
+
+
+def upsample_concat_fwd(u, skip, out):
+    N, h, w, Cu = u.shape
+    L.check(L.load().mgd_upsample_concat_fwd(L.ptr(u), L.ptr(skip), L.ptr(out), N, h, w, Cu, skip.shape[-1],
+                                             L.stream_ptr()), "upsample_concat_fwd")
+    return out
+
+
+def upsample_concat_bwd(dout, du, dskip):
+    N, h, w, Cu = du.shape
+    L.check(L.load().mgd_upsample_concat_bwd(L.ptr(dout), L.ptr(du), L.ptr(dskip), N, h, w, Cu, dskip.shape[-1],
+                                             L.stream_ptr()), "upsample_concat_bwd")
+
+
+def bias_grad(dy, dbias):
+    Cn = dy.shape[-1]
+    L.check(L.load().mgd_bias_grad(L.ptr(dy), L.ptr(dbias), C.c_int64(dy.numel() // Cn), Cn, L.stream_ptr()),
+            "bias_grad")
+
+
+def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0, weight_decay=0.0):
+    L.check(L.load().mgd_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), C.c_int64(p.numel()), C.c_float(lr),
+                                   C.c_float(b1), C.c_float(b2), C.c_float(eps), int(step), C.c_float(grad_scale),
+                                   C.c_float(weight_decay), L.stream_ptr()), "adam")
+
+
+def sgd_step(p, g, mom, lr, momentum=0.937, nesterov=True, grad_scale=1.0):
+    L.check(L.load().mgd_sgd_step(L.ptr(p), L.ptr(g), L.ptr(mom), C.c_int64(p.numel()), C.c_float(lr),
+                                  C.c_float(momentum), int(nesterov), C.c_float(grad_scale), L.stream_ptr()), "sgd")
+
+
+# ------------------------------------------------------------------------------------------- targets
+def _anchor_array(anchors):
+    a = np.stack([np.asarray(x, dtype=np.float32) for x in anchors], 0)   # [L, A, 2]
+    return a
+
+
+def build_targets(boxes, input_shape, anchors, num_classes, grid_shapes=None, mode=0, return_assignment=False):
+    """boxes: fp32 CUDA [B, M, 5] -> list of fp32 [B, gh, gw, 5+A+C]."""
+    L.require_gpu()
+    lib = L.load()
+    B, M, _ = boxes.shape
+    a = _anchor_array(anchors)
+    nl, A = a.shape[0], a.shape[1]
+    H, W = int(input_shape[0]), int(input_shape[1])
+    if grid_shapes is None:
+        grid_shapes = [(H // s, W // s) for s in (32, 16, 8)][:nl]
+    ghw = (C.c_int32 * (2 * nl))(*[int(v) for g in grid_shapes for v in g])
+    F = 5 + A + num_classes
+    ys = [torch.empty(B, int(g[0]), int(g[1]), F, dtype=torch.float32, device=boxes.device) for g in grid_shapes]
+    need = lib.mgd_build_targets_workspace_size(B, M, nl, ghw)
+    ws = torch.empty(need, dtype=torch.uint8, device=boxes.device)
+    assign = torch.empty(B, M, 4, dtype=torch.int32, device=boxes.device) if return_assignment else None
+    yp = (C.c_void_p * nl)(*[y.data_ptr() for y in ys])
+    af = a.reshape(-1)
+    L.check(lib.mgd_build_targets(L.ptr(boxes.contiguous()), B, M, af.ctypes.data_as(C.POINTER(C.c_float)), nl, A,
+                                  num_classes, H, W, ghw, yp, L.ptr(assign), mode, L.ptr(ws), C.c_size_t(need),
+                                  L.stream_ptr()), "build_targets")
+    if return_assignment:
+        return ys, assign
+    return ys
+
+
+# ------------------------------------------------------------------------------------------- loss
+def make_loss_cfg(anchors, num_classes, input_shape, batch, grid_shapes, **kw):
+    a = _anchor_array(anchors)
+    cfg = L.LossCfg()
+    cfg.L, cfg.A, cfg.C, cfg.B = a.shape[0], a.shape[1], num_classes, batch
+    cfg.in_h, cfg.in_w = int(input_shape[0]), int(input_shape[1])
+    for l, g in enumerate(grid_shapes):
+        cfg.grid_h[l], cfg.grid_w[l] = int(g[0]), int(g[1])
+        for j in range(a.shape[1]):
+            cfg.anchors[l][j][0], cfg.anchors[l][j][1] = float(a[l, j, 0]), float(a[l, j, 1])
+    norm = kw.get("loss_normalization") or ["batch"]
+    if not isinstance(norm, list):
+        norm = [norm]
+    cfg.norm_batch, cfg.norm_positives, cfg.norm_grid = norm.count("batch"), norm.count("positives"), norm.count("grid")
+    cfg.ignore_thresh = kw.get("ignore_thresh", 0.5)
+    cfg.label_smoothing = kw.get("label_smoothing", 0.0)
+    cfg.loss_option = kw.get("loss_option", 2)
+    for k, dflt in (("coord_scale", 1.0), ("object_scale", 1.0), ("no_object_scale", 1.0), ("class_scale", 1.0),
+                    ("anchor_scale", 1.0), ("iou_objectness_power", 1.0), ("trainable_nms_power", 2.0),
+                    ("consensus_iou_power", 1.5), ("consensus_min_iou", 1e-3), ("consensus_coord_scale", 0.5),
+                    ("consensus_obj_scale", 0.5), ("consensus_class_scale", 0.3),
+                    ("consensus_center_tolerance", 1e-4), ("focal_alpha", 0.25), ("focal_gamma", 2.0)):
+        setattr(cfg, k, float(kw.get(k, dflt)))
+    cfg.iou_objectness_ratio = float(min(max(kw.get("iou_objectness_ratio", 1.0), 0.0), 1.0))
+    cfg.trainable_nms_weight = float(kw.get("trainable_nms_weight", 0.0))
+    cfg.use_iou_aware_objectness = int(bool(kw.get("use_iou_aware_objectness", False)))
+    cfg.use_consensus_loss = int(bool(kw.get("use_consensus_loss", False)))
+    cfg.consensus_stop_gradient = int(bool(kw.get("consensus_stop_gradient", True)))
+    cfg.use_focal_loss = int(bool(kw.get("use_focal_loss", False)))
+    cfg.grad_out_scale = float(kw.get("grad_out_scale", 1.0))
+    return cfg
+
+
+class LossRunner:
+    """Holds the workspace; `run` returns (components[8] device tensor, grads)."""
+
+    def __init__(self, cfg, device, class_weights=None):
+        self.cfg = cfg
+        lib = L.load()
+        self.need = lib.mgd_loss_workspace_size(C.byref(cfg))
+        self.ws = torch.empty(self.need, dtype=torch.uint8, device=device)
+        self.components = torch.zeros(8, dtype=torch.float32, device=device)
+        self.class_weights = None if class_weights is None else torch.as_tensor(
+            class_weights, dtype=torch.float32, device=device).contiguous()
+
+    def run(self, y_true, y_pred, grad_f32=None, grad_bf16=None):
+        nl = self.cfg.L
+        yp = (C.c_void_p * nl)(*[t.data_ptr() for t in y_pred])
+        yt = (C.c_void_p * nl)(*[t.data_ptr() for t in y_true])
+        gf = (C.c_void_p * nl)(*[t.data_ptr() for t in grad_f32]) if grad_f32 is not None else None
+        gb = (C.c_void_p * nl)(*[t.data_ptr() for t in grad_bf16]) if grad_bf16 is not None else None
+        L.check(L.load().mgd_loss_fwd_bwd(C.byref(self.cfg), yp, yt, L.ptr(self.class_weights), gf, gb,
+                                          L.ptr(self.components), L.ptr(self.ws), C.c_size_t(self.need),
+                                          L.stream_ptr()), "loss_fwd_bwd")
+        return self.components
+
+
+# ------------------------------------------------------------------------------------------- decode / nms
+def make_decode_cfg(anchors, num_classes, input_shape, batch, grid_shapes, confidence, use_softmax=True,
+                    rescore=True, cap=None):
+    a = _anchor_array(anchors)
+    cfg = L.DecodeCfg()
+    cfg.L, cfg.A, cfg.C, cfg.B = a.shape[0], a.shape[1], num_classes, batch
+    cfg.in_h, cfg.in_w = int(input_shape[0]), int(input_shape[1])
+    tot = 0
+    for l, g in enumerate(grid_shapes):
+        cfg.grid_h[l], cfg.grid_w[l] = int(g[0]), int(g[1])
+        tot += int(g[0]) * int(g[1])
+        for j in range(a.shape[1]):
+            cfg.anchors[l][j][0], cfg.anchors[l][j][1] = float(a[l, j, 0]), float(a[l, j, 1])
+    cfg.use_softmax, cfg.rescore = int(use_softmax), int(rescore)
+    cfg.confidence = float(confidence)
+    cfg.cap = int(cap if cap is not None else tot)
+    return cfg
+
+
+def decode(cfg, y_pred, image_hw):
+    """y_pred: list of fp32 CUDA [B,g,g,F]; image_hw: fp32 CUDA [B,2] -> (boxes[B,cap,4], scores, cls, count)."""
+    lib = L.load()
+    dev = y_pred[0].device
+    need = lib.mgd_decode_workspace_size(C.byref(cfg))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    B, cap = cfg.B, cfg.cap
+    boxes = torch.zeros(B, cap, 4, dtype=torch.float32, device=dev)
+    scores = torch.zeros(B, cap, dtype=torch.float32, device=dev)
+    cls = torch.zeros(B, cap, dtype=torch.int32, device=dev)
+    count = torch.zeros(B, dtype=torch.int32, device=dev)
+    yp = (C.c_void_p * cfg.L)(*[t.data_ptr() for t in y_pred])
+    L.check(lib.mgd_decode(C.byref(cfg), yp, L.ptr(image_hw), L.ptr(boxes), L.ptr(scores), L.ptr(cls), L.ptr(count),
+                           L.ptr(ws), C.c_size_t(need), L.stream_ptr()), "decode")
+    return boxes, scores, cls, count
+
+
+NMS_METHODS = {"standard": 0, "cluster": 0, "iou": 0, "diou": 1}
+
+
+def nms(boxes, scores, cls, count, image_hw, method="diou", threshold=0.5, max_boxes=100, return_xyxy=True):
+    lib = L.load()
+    B, cap = scores.shape
+    dev = boxes.device
+    need = lib.mgd_nms_workspace_size(B, cap)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    ob = torch.zeros(B, max_boxes, 4, dtype=torch.int32 if return_xyxy else torch.float32, device=dev)
+    osc = torch.zeros(B, max_boxes, dtype=torch.float32, device=dev)
+    ocl = torch.zeros(B, max_boxes, dtype=torch.int32, device=dev)
+    ocn = torch.zeros(B, dtype=torch.int32, device=dev)
+    L.check(lib.mgd_nms(L.ptr(boxes), L.ptr(scores), L.ptr(cls), L.ptr(count), B, cap, NMS_METHODS[method],
+                        C.c_float(threshold), max_boxes, L.ptr(image_hw), int(return_xyxy), L.ptr(ob), L.ptr(osc),
+                        L.ptr(ocl), L.ptr(ocn), L.ptr(ws), C.c_size_t(need), L.stream_ptr()), "nms")
+    return ob, osc, ocl, ocn
