@@ -146,17 +146,18 @@ __global__ void t2_assign_kernel(TgtArgs a) {
   }
 }
 
-// Dense write: one thread = 4 consecutive channels of one cell (F % 4 == 0).
+// Dense write: one thread = VEC consecutive channels of one cell (VEC = 4 when F % 4 == 0, else 1).
+template <int VEC>
 __global__ __launch_bounds__(256) void write_dense_kernel(TgtArgs a, int layer) {
   const int gh = a.gh[layer], gw = a.gw[layer];
-  const int F = 5 + a.A + a.C, FV = F >> 2;
+  const int F = 5 + a.A + a.C, FV = F / VEC;
   const long long ncell = (long long)a.B * gh * gw;
   const long long nvec = ncell * FV;
   float* y = a.y[layer];
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
     long long cell = i / FV;
-    int c0 = (int)(i - cell * FV) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int c0 = (int)(i - cell * FV) * VEC;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
     int key = a.owner[a.cell_off[layer] + cell];
     if (key != 0) {
       int b = (int)(cell / ((long long)gh * gw));
@@ -164,9 +165,8 @@ __global__ __launch_bounds__(256) void write_dense_kernel(TgtArgs a, int layer) 
       const float* info = a.boxinfo + ((long long)b * a.M + t) * 12;
       const double txd = ((const double*)info)[0], tyd = ((const double*)info)[1];
       int k = (int)info[7], cls = (int)info[8];
-      float o[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < VEC; ++j) {
         int c = c0 + j;
         float val = 0.f;
         if (a.mode == 0) {
@@ -187,9 +187,9 @@ __global__ __launch_bounds__(256) void write_dense_kernel(TgtArgs a, int layer) 
         else if (c >= 5 + a.A) val = (c - 5 - a.A == cls && cls >= 0 && cls < a.C) ? 1.f : 0.f;
         o[j] = val;
       }
-      v = make_float4(o[0], o[1], o[2], o[3]);
     }
-    *(float4*)(y + cell * F + c0) = v;
+    if (VEC == 4) *(float4*)(y + cell * F + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    else y[cell * F + c0] = o[0];
   }
 }
 #pragma clang fp contract(fast)
@@ -217,7 +217,6 @@ extern "C" int mgd_build_targets(const float* boxes, int B, int M, const float* 
                                  int32_t* assign, int mode, void* ws, size_t ws_bytes, void* stream) {
   MGD_REQUIRE(boxes && anchors_host && grid_hw_host && y_true_host && ws, "build_targets: null pointer");
   MGD_REQUIRE(L >= 1 && L <= MAXL && A >= 1 && A <= MAXA, "build_targets: L=%d A=%d unsupported", L, A);
-  MGD_REQUIRE((5 + A + C) % 4 == 0, "build_targets: 5+A+C=%d must be a multiple of 4", 5 + A + C);
   MGD_REQUIRE(mode == 0 || mode == 1, "build_targets: mode");
   MGD_REQUIRE(M >= 1 && M * 9 + 1 < (1 << 30), "build_targets: M");
   TgtArgs a;
@@ -246,10 +245,12 @@ extern "C" int mgd_build_targets(const float* boxes, int B, int M, const float* 
   if (mode == 0) hipLaunchKernelGGL(t1_claim_kernel, dim3(cdiv((long)B * M, 128)), dim3(128), 0, st, a);
   else hipLaunchKernelGGL(t2_assign_kernel, dim3(B), dim3(64), 0, st, a);
   for (int l = 0; l < L; ++l) {
-    long long nvec = (long long)B * a.gh[l] * a.gw[l] * ((5 + A + C) / 4);
+    const int F = 5 + A + C, vec = (F % 4 == 0) ? 4 : 1;
+    long long nvec = (long long)B * a.gh[l] * a.gw[l] * (F / vec);
     long long g = (nvec + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(write_dense_kernel, dim3((int)g), dim3(256), 0, st, a, l);
+    if (vec == 4) hipLaunchKernelGGL(write_dense_kernel<4>, dim3((int)g), dim3(256), 0, st, a, l);
+    else hipLaunchKernelGGL(write_dense_kernel<1>, dim3((int)g), dim3(256), 0, st, a, l);
   }
   MGD_CHECK_LAUNCH("build_targets");
   return MGD_OK;

@@ -1,0 +1,450 @@
+"""Static executor of the Darknet53 + FPN + DenseYOLO-head graph on libmgd_hip.so.
+
+The reference builds this graph with Keras layers and lets TensorFlow differentiate it
+(multigriddet/models/backbones/darknet.py:19-40, models/heads/multigrid_head.py:38-74, 275-313,
+models/multigriddet_darknet.py:488-548).  Here the topology is fixed at construction, every
+activation lives in a pre-allocated NHWC bf16 arena sized for the resolution in use, parameters /
+gradients / optimiser state are three flat fp32 buffers (so the optimiser is one launch and the
+data-parallel all-reduce works on contiguous slices), and forward/backward are explicit sequences of
+C-ABI calls - no autograd tape, no tracing compiler.  torch is the allocator and stream provider.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+
+STAGES = ((64, 1), (128, 2), (256, 8), (512, 8), (1024, 4))
+BACKBONE_CONVS = 52
+
+
+def conv_specs(num_classes=80, num_anchors=3):
+    """Conv list in graph-construction order (same order as the reference's Keras layer creation)."""
+    specs = []
+
+    def c(cin, cout, k, s=1, bn=True, role=""):
+        specs.append(dict(cin=cin, cout=cout, k=k, s=s, bn=bn, role=role))
+
+    c(3, 32, 3, role="stem")
+    ch = 32
+    for f, n in STAGES:
+        c(ch, f, 3, 2, role="down")
+        for _ in range(n):
+            c(f, f // 2, 1, role="res1")
+            c(f // 2, f, 3, role="res2")
+        ch = f
+    out = num_anchors + num_classes + 5
+    cin = 1024
+    for n, mult, skip in ((256, 8, 512), (128, 4, 256), (64, 2, None)):
+        c(cin, n, 1, role="h1")
+        c(n, 2 * n, 3, role="h2")
+        c(2 * n, n, 1, role="h3")
+        c(n, mult * out, 3, role="h4")
+        c(mult * out, out, 1, bn=False, role="pred")
+        if skip is not None:
+            c(n, n // 2, 1, role="lat")
+            cin = n // 2 + skip
+    return specs
+
+
+class Conv:
+    """One conv (+BN+LeakyReLU) with views into the flat parameter / gradient buffers."""
+    pass
+
+
+class Network:
+    def __init__(self, num_classes=80, num_anchors=3, device="cuda:0", seed=0):
+        L.require_gpu()
+        L.load()
+        self.device = torch.device(device)
+        self.num_classes, self.num_anchors = num_classes, num_anchors
+        self.out_ch = num_anchors + num_classes + 5
+        self.specs = conv_specs(num_classes, num_anchors)
+        # ---- flat parameter layout
+        off = 0
+        self.layers = []
+        for i, sp in enumerate(self.specs):
+            cv = Conv()
+            cv.idx, cv.cin, cv.cout, cv.k, cv.s, cv.bn, cv.role = i, sp["cin"], sp["cout"], sp["k"], sp["s"], sp["bn"], sp["role"]
+            cv.T = cv.k * cv.k
+            cv.off_w = off
+            off += cv.cout * cv.T * cv.cin
+            cv.off_a = off          # gamma | bias
+            off += cv.cout
+            if cv.bn:
+                cv.off_b = off      # beta
+                off += cv.cout
+            cv.end = off
+            self.layers.append(cv)
+        self.n_params = off
+        self.backbone_end = self.layers[BACKBONE_CONVS - 1].end
+        dev = self.device
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        n_bn = sum(l.cout for l in self.layers if l.bn)
+        self.moving = torch.zeros(2 * n_bn, dtype=torch.float32, device=dev)
+        self.bnwork = torch.zeros(4 * n_bn, dtype=torch.float32, device=dev)          # scale, shift, mean, invstd
+        R = ops.STATS_REPLICAS
+        self.stats_all = torch.zeros(n_bn * (2 * R + 2 * (R + 1)), dtype=torch.float32, device=dev)
+        bo, so = 0, 0
+        for cv in self.layers:
+            C = cv.cout
+            cv.w = self.params[cv.off_w:cv.off_w + C * cv.T * cv.cin].view(C, cv.T, cv.cin)
+            cv.dw = self.grads[cv.off_w:cv.off_w + C * cv.T * cv.cin].view(C, cv.T, cv.cin)
+            if cv.bn:
+                cv.gamma, cv.beta = self.params[cv.off_a:cv.off_a + C], self.params[cv.off_b:cv.off_b + C]
+                cv.dgamma, cv.dbeta = self.grads[cv.off_a:cv.off_a + C], self.grads[cv.off_b:cv.off_b + C]
+                cv.mm, cv.mv = self.moving[bo:bo + C], self.moving[n_bn + bo:n_bn + bo + C]
+                cv.scale, cv.shift = self.bnwork[bo:bo + C], self.bnwork[n_bn + bo:n_bn + bo + C]
+                cv.smean, cv.sinv = self.bnwork[2 * n_bn + bo:2 * n_bn + bo + C], self.bnwork[3 * n_bn + bo:3 * n_bn + bo + C]
+                cv.stats = self.stats_all[so:so + 2 * R * C].view(R, 2, C)
+                so += 2 * R * C
+                cv.sums = self.stats_all[so:so + 2 * (R + 1) * C]
+                so += 2 * (R + 1) * C
+                bo += C
+            else:
+                cv.bias = self.params[cv.off_a:cv.off_a + C]
+                cv.dbias = self.grads[cv.off_a:cv.off_a + C]
+            cv.pk = None if cv.role == "stem" else ops.PackedConv(cv.cout, cv.cin, cv.k, cv.s, dev, need_dgrad=(i != 1) or True)
+        self.training = True
+        self.freeze_backbone = False
+        self.freeze_all_but_pred = False
+        self._arenas = {}
+        self.reset_parameters(seed)
+
+    # ------------------------------------------------------------------ parameters
+    def reset_parameters(self, seed=0):
+        """Glorot-uniform kernels (Keras default), gamma=1, beta=0, bias=0, moving mean 0 / var 1."""
+        rng = np.random.default_rng(seed)
+        host = np.zeros(self.n_params, np.float32)
+        for cv in self.layers:
+            lim = math.sqrt(6.0 / (cv.T * cv.cin + cv.T * cv.cout))
+            k = rng.uniform(-lim, lim, size=(cv.k, cv.k, cv.cin, cv.cout)).astype(np.float32)   # Keras HWIO
+            host[cv.off_w:cv.off_w + k.size] = np.transpose(k, (3, 0, 1, 2)).reshape(-1)       # -> OHWI
+            if cv.bn:
+                host[cv.off_a:cv.off_a + cv.cout] = 1.0
+        self.params.copy_(torch.from_numpy(host))
+        n_bn = self.moving.numel() // 2
+        self.moving[:n_bn] = 0.0
+        self.moving[n_bn:] = 1.0
+        self.refresh_packed()
+
+    def load_keras_style(self, plist):
+        """plist: list (graph order) of dicts with 'kernel' (kh,kw,cin,cout) and gamma/beta/moving_* or bias."""
+        host = self.params.cpu().numpy().copy()
+        mov = self.moving.cpu().numpy().copy()
+        n_bn = mov.size // 2
+        bo = 0
+        for cv, p in zip(self.layers, plist):
+            k = np.asarray(p["kernel"], np.float32)
+            host[cv.off_w:cv.off_w + k.size] = np.transpose(k, (3, 0, 1, 2)).reshape(-1)
+            if cv.bn:
+                host[cv.off_a:cv.off_a + cv.cout] = p["gamma"]
+                host[cv.off_b:cv.off_b + cv.cout] = p["beta"]
+                mov[bo:bo + cv.cout] = p["moving_mean"]
+                mov[n_bn + bo:n_bn + bo + cv.cout] = p["moving_var"]
+                bo += cv.cout
+            else:
+                host[cv.off_a:cv.off_a + cv.cout] = p["bias"]
+        self.params.copy_(torch.from_numpy(host))
+        self.moving.copy_(torch.from_numpy(mov))
+        self.refresh_packed()
+
+    def export_keras_style(self):
+        host = self.params.cpu().numpy()
+        out = []
+        for cv in self.layers:
+            w = host[cv.off_w:cv.off_w + cv.cout * cv.T * cv.cin].reshape(cv.cout, cv.k, cv.k, cv.cin)
+            p = {"kernel": np.transpose(w, (1, 2, 3, 0)).copy()}
+            if cv.bn:
+                p["gamma"] = host[cv.off_a:cv.off_a + cv.cout].copy()
+                p["beta"] = host[cv.off_b:cv.off_b + cv.cout].copy()
+                p["moving_mean"] = cv.mm.cpu().numpy().copy()
+                p["moving_var"] = cv.mv.cpu().numpy().copy()
+            else:
+                p["bias"] = host[cv.off_a:cv.off_a + cv.cout].copy()
+            out.append(p)
+        return out
+
+    def refresh_packed(self, first=0):
+        for cv in self.layers[first:]:
+            if cv.pk is not None:
+                cv.pk.refresh(cv.w)
+
+    def count_params(self):
+        return self.n_params + self.moving.numel()
+
+    def trainable_range(self):
+        """[begin, end) slice of the flat buffers that the optimiser updates."""
+        if self.freeze_all_but_pred:
+            return None     # handled per layer (three disjoint slices)
+        return (self.backbone_end if self.freeze_backbone else 0, self.n_params)
+
+    # ------------------------------------------------------------------ arena
+    def arena(self, B, H, W):
+        key = (B, H, W)
+        if key in self._arenas:
+            return self._arenas[key]
+        dev = self.device
+        A = {"y": {}, "a": {}, "hw": {}}
+        bf = torch.bfloat16
+
+        def alloc(i, h, w):
+            cv = self.layers[i]
+            A["hw"][i] = (h, w)
+            if cv.bn:
+                A["y"][i] = torch.empty(B, h, w, cv.cout, dtype=bf, device=dev)
+                A["a"][i] = torch.empty(B, h, w, cv.cout, dtype=bf, device=dev)
+            else:
+                A["y"][i] = torch.empty(B, h, w, cv.cout, dtype=torch.float32, device=dev)
+
+        i = 0
+        alloc(0, H, W)
+        h, w = H, W
+        i = 1
+        for f, n in STAGES:
+            h, w = h // 2, w // 2
+            alloc(i, h, w)
+            i += 1
+            for _ in range(n):
+                alloc(i, h, w)
+                alloc(i + 1, h, w)
+                i += 2
+        gh, gw = H // 32, W // 32
+        A["cat"] = {}
+        for sc in range(3):
+            for j in range(5):
+                alloc(i + j, gh, gw)
+            i += 5
+            if sc < 2:
+                alloc(i, gh, gw)
+                lat = self.layers[i]
+                skip_c = 512 if sc == 0 else 256
+                A["cat"][sc] = torch.empty(B, 2 * gh, 2 * gw, lat.cout + skip_c, dtype=bf, device=dev)
+                i += 1
+                gh, gw = gh * 2, gw * 2
+        A["scratch"] = {}
+        self._arenas[key] = A
+        return A
+
+    def _scratch(self, A, tag, shape, dtype=torch.bfloat16):
+        key = (tag, tuple(shape), dtype)
+        t = A["scratch"].get(key)
+        if t is None:
+            t = torch.empty(*shape, dtype=dtype, device=self.device)
+            A["scratch"][key] = t
+        return t
+
+    # ------------------------------------------------------------------ forward
+    def _bn_training(self, cv):
+        if not self.training:
+            return False
+        if self.freeze_all_but_pred:
+            return False
+        if self.freeze_backbone and cv.idx < BACKBONE_CONVS:
+            return False           # Keras: trainable=False puts BatchNormalization in inference mode
+        return True
+
+    def _conv_bn_act(self, A, i, x, residual=None):
+        cv = self.layers[i]
+        tr = self._bn_training(cv)
+        y = A["y"][i]
+        if cv.role == "stem":
+            ops.stem_fwd(x, cv.w, out=y, stats=cv.stats if tr else None)
+        else:
+            ops.conv_fwd(x, cv.pk, out=y, stats=cv.stats if tr else None)
+        P = y.numel() // cv.cout
+        ops.bn_finalize(cv.stats, float(P), cv.gamma, cv.beta, cv.mm, cv.mv, cv.scale, cv.shift, cv.smean, cv.sinv,
+                        training=tr)
+        return ops.bn_act_fwd(y, cv.scale, cv.shift, A["a"][i], residual=residual)
+
+    def forward(self, images):
+        """images: fp32 CUDA [B,H,W,3] in [0,1].  Returns [y1, y2, y3] raw head tensors (fp32 NHWC)."""
+        B, H, W, _ = images.shape
+        assert H % 32 == 0 and W % 32 == 0
+        A = self.arena(B, H, W)
+        A["image"] = images
+        self.stats_all.zero_()
+        x = self._conv_bn_act(A, 0, images)
+        i = 1
+        feats = {}
+        for f, n in STAGES:
+            x = self._conv_bn_act(A, i, x)
+            i += 1
+            for _ in range(n):
+                a1 = self._conv_bn_act(A, i, x)
+                x = self._conv_bn_act(A, i + 1, a1, residual=x)
+                i += 2
+            feats[f] = x
+        skips = (feats[512], feats[256])
+        x = feats[1024]
+        outs = []
+        for sc in range(3):
+            x = self._conv_bn_act(A, i, x)
+            x = self._conv_bn_act(A, i + 1, x)
+            xb = self._conv_bn_act(A, i + 2, x)
+            a4 = self._conv_bn_act(A, i + 3, xb)
+            pred = self.layers[i + 4]
+            outs.append(ops.conv_fwd(a4, pred.pk, out=A["y"][i + 4], bias=pred.bias, out_f32=True))
+            i += 5
+            if sc < 2:
+                a6 = self._conv_bn_act(A, i, xb)
+                x = ops.upsample_concat_fwd(a6, skips[sc], A["cat"][sc])
+                i += 1
+        A["outs"] = outs
+        self._last = A
+        return outs
+
+    # ------------------------------------------------------------------ backward
+    def _bwd_bn(self, A, i, da):
+        """da: grad wrt the activated output of layer i -> returns dy (grad wrt the raw conv output)."""
+        cv = self.layers[i]
+        y = A["y"][i]
+        dy = self._scratch(A, "dy", y.shape)
+        frozen = not self._bn_training(cv)
+        ops.bn_act_bwd(da, y, cv.scale, cv.shift, cv.smean, cv.sinv, cv.sums, cv.dgamma, cv.dbeta, dy, frozen=frozen)
+        return dy
+
+    def _input_of(self, A, i):
+        """Activation tensor that layer i consumed in forward."""
+        return A["in"][i]
+
+    def backward(self, douts, on_layer_done=None):
+        """douts: three bf16 grads wrt the head outputs.  Accumulates into self.grads (zero it first).
+        on_layer_done(i) is called when every gradient of layers >= i is final (DP bucket hook)."""
+        A = self._last
+        Lr = self.layers
+        B = douts[0].shape[0]
+        acts = A["a"]
+        hw = A["hw"]
+        train_head_only = self.freeze_backbone
+        pred_only = self.freeze_all_but_pred
+
+        def inp(i):
+            return self._fwd_inputs[i]
+
+        # rebuild the forward wiring (indices only)
+        if not hasattr(self, "_fwd_inputs"):
+            self._wire()
+        head0 = BACKBONE_CONVS
+        d_up = {}            # grads for lateral activations, keyed by scale
+        d_skip = {}          # grads for the backbone taps
+        g_f1 = None
+        for sc in (2, 1, 0):
+            base = head0 + sc * 6
+            c1, c2, c3, c4, c5 = base, base + 1, base + 2, base + 3, base + 4
+            pred = Lr[c5]
+            dy5 = douts[sc]
+            a4 = acts[c4]
+            ops.bias_grad(dy5, pred.dbias)
+            ops.conv_wgrad(a4, dy5, pred.dw, 1, 1)
+            if on_layer_done and pred_only:
+                on_layer_done(c5)
+            if pred_only:
+                continue
+            d_a4 = ops.conv_dgrad(dy5, pred.pk, hw[c4], out=self._scratch(A, "da_a", a4.shape))
+            dy4 = self._bwd_bn(A, c4, d_a4)
+            xb = acts[c3]
+            ops.conv_wgrad(xb, dy4, Lr[c4].dw, 3, 1)
+            d_xb = ops.conv_dgrad(dy4, Lr[c4].pk, hw[c3], out=self._scratch(A, "da_b", xb.shape))
+            if sc < 2:
+                c6 = base + 5
+                dy6 = self._bwd_bn(A, c6, d_up[sc])
+                ops.conv_wgrad(xb, dy6, Lr[c6].dw, 1, 1)
+                ops.conv_dgrad(dy6, Lr[c6].pk, hw[c3], out=d_xb, addend=d_xb)
+            dy3 = self._bwd_bn(A, c3, d_xb)
+            a2 = acts[c2]
+            ops.conv_wgrad(a2, dy3, Lr[c3].dw, 1, 1)
+            d_a2 = ops.conv_dgrad(dy3, Lr[c3].pk, hw[c2], out=self._scratch(A, "da_a", a2.shape))
+            dy2 = self._bwd_bn(A, c2, d_a2)
+            a1 = acts[c1]
+            ops.conv_wgrad(a1, dy2, Lr[c2].dw, 3, 1)
+            d_a1 = ops.conv_dgrad(dy2, Lr[c2].pk, hw[c1], out=self._scratch(A, "da_b", a1.shape))
+            dy1 = self._bwd_bn(A, c1, d_a1)
+            xin = A["cat"][sc - 1] if sc > 0 else acts[BACKBONE_CONVS - 1]
+            ops.conv_wgrad(xin, dy1, Lr[c1].dw, 1, 1)
+            if on_layer_done:
+                on_layer_done(c1)
+            if sc > 0:
+                d_cat = ops.conv_dgrad(dy1, Lr[c1].pk, hw[c1], out=self._scratch(A, "dcat", xin.shape))
+                lat = Lr[head0 + (sc - 1) * 6 + 5]
+                gh, gw = hw[lat.idx]
+                du = self._scratch(A, f"du{sc}", (B, gh, gw, lat.cout))
+                skip_c = xin.shape[-1] - lat.cout
+                dsk = self._scratch(A, f"dskip{sc}", (B, 2 * gh, 2 * gw, skip_c))
+                if train_head_only:
+                    ops.upsample_concat_bwd(d_cat, du, dsk)
+                else:
+                    ops.upsample_concat_bwd(d_cat, du, dsk)
+                    d_skip[sc - 1] = dsk
+                d_up[sc - 1] = du
+            elif not train_head_only:
+                g_f1 = ops.conv_dgrad(dy1, Lr[c1].pk, hw[c1], out=self._scratch(A, "g5", acts[BACKBONE_CONVS - 1].shape))
+        if pred_only or train_head_only:
+            if on_layer_done:
+                on_layer_done(0)
+            return
+        # ---- backbone, last stage first.  g = grad wrt the running residual sum x.
+        g = g_f1
+        i = BACKBONE_CONVS - 1
+        for st in range(len(STAGES) - 1, -1, -1):
+            f, n = STAGES[st]
+            for _ in range(n):
+                l2, l1 = i, i - 1
+                x_in = inp(l1)
+                dy2 = self._bwd_bn(A, l2, g)                     # residual branch: d a2 = g
+                a1 = acts[l1]
+                ops.conv_wgrad(a1, dy2, Lr[l2].dw, 3, 1)
+                d_a1 = ops.conv_dgrad(dy2, Lr[l2].pk, hw[l1], out=self._scratch(A, "da_a", a1.shape))
+                dy1 = self._bwd_bn(A, l1, d_a1)
+                ops.conv_wgrad(x_in, dy1, Lr[l1].dw, 1, 1)
+                ops.conv_dgrad(dy1, Lr[l1].pk, hw[l1], out=g, addend=g)      # g <- g + dgrad (in place)
+                if on_layer_done:
+                    on_layer_done(l1)
+                i -= 2
+            ld = i
+            x_prev = inp(ld)
+            dyd = self._bwd_bn(A, ld, g)
+            if st == 0:
+                ops.conv_wgrad(x_prev, dyd, Lr[ld].dw, 3, 2)
+                g = ops.conv_dgrad(dyd, Lr[ld].pk, hw[0], out=self._scratch(A, "g0", x_prev.shape))
+            else:
+                ops.conv_wgrad(x_prev, dyd, Lr[ld].dw, 3, 2)
+                add = None
+                if st == 4:
+                    add = d_skip[0]      # f2 (stage-4 output) also fed the scale-2 concat
+                elif st == 3:
+                    add = d_skip[1]      # f3 (stage-3 output) also fed the scale-3 concat
+                g = ops.conv_dgrad(dyd, Lr[ld].pk, hw[ld - 1], out=self._scratch(A, f"g{st}", x_prev.shape), addend=add)
+            if on_layer_done:
+                on_layer_done(ld)
+            i -= 1
+        dy0 = self._bwd_bn(A, 0, g)
+        ops.stem_wgrad(A["image"], dy0, Lr[0].dw)
+        if on_layer_done:
+            on_layer_done(0)
+
+    def _wire(self):
+        """Forward input activation of each backbone conv (index into A['a']), resolved lazily."""
+        A = self._last
+        acts = A["a"]
+        fin = {}
+        i = 1
+        prev = 0
+        for f, n in STAGES:
+            fin[i] = acts[prev]
+            x = i
+            i += 1
+            for _ in range(n):
+                fin[i] = acts[x]
+                fin[i + 1] = acts[i]
+                x = i + 1
+                i += 2
+            prev = x
+        self._fwd_inputs = fin
+        self._wired_for = id(A)
+
+    def zero_grad(self):
+        self.grads.zero_()
