@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py - images/sec of one MultiGridDet train step (fwd + MultiGridLoss + bwd + Adam) at 608x608,
+batch 16 per GPU, on N MI355X of one node (BASELINE.json `metric`).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Inputs (synthetic COCO-shaped images + boxes) are resident in HBM before
+the timed region.  `roofline` is for the dominant kernel (the 128x128-tile bf16 MFMA gather-GEMM that
+runs the 3x3 convolutions and their data gradients): algorithmic conv FLOPs of its launches / their
+summed durations, measured with HIP events on the launch stream inside the timed region.
+`cpu_baseline` times the oracle (torch-CPU restatement of the same train step) on the host cores, rank 0,
+N=1 only, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SIZE = 608
+BATCH = 16
+FLOP_PER_IMAGE_FWD = 112.111328256e9          # 69 convs at 608^2
+PEAK_BF16_TFLOPS = 2500.0                     # dense bf16 MFMA, MI355X_MICROARCH.md
+
+
+def coco_anchors():
+    return [np.array([[112, 74], [149, 190], [370, 328]], np.float32),
+            np.array([[28, 17], [56, 112], [57, 35]], np.float32),
+            np.array([[9, 10], [13, 28], [28, 55]], np.float32)]
+
+
+def synth_batch(rank, batch, size, max_boxes=100):
+    """images default_rng(0) (+rank), boxes n~U{1..20}, w,h=exp(U(ln8, ln400))."""
+    rng = np.random.default_rng(0 + rank)
+    images = rng.random((batch, size, size, 3), dtype=np.float32)
+    rng = np.random.default_rng(1 + rank)
+    boxes = np.zeros((batch, max_boxes, 5), np.float32)
+    for b in range(batch):
+        for t in range(int(rng.integers(1, 21))):
+            w = min(float(np.exp(rng.uniform(np.log(8), np.log(400)))), size - 2)
+            h = min(float(np.exp(rng.uniform(np.log(8), np.log(400)))), size - 2)
+            cx, cy = rng.uniform(w / 2, size - w / 2), rng.uniform(h / 2, size - h / 2)
+            boxes[b, t] = [cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, rng.integers(0, 80)]
+    return images, boxes
+
+
+def cpu_baseline(size, sample_batch=2):
+    """Oracle train step (torch-CPU fp32 conv/BN/autograd + restated loss/targets + Adam) on the host."""
+    from oracle import model as om
+    from oracle.loss import MultiGridLossOracle
+    from oracle import targets as ot
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    images, boxes = synth_batch(0, sample_batch, size)
+    params = om.torch_params(om.init_params(0), requires_grad=True)
+    lo = MultiGridLossOracle(coco_anchors(), 80, (size, size))
+    state = {}
+
+    def one():
+        yt = ot.tf_preprocess_true_boxes(boxes, (size, size), coco_anchors(), 80)
+        outs = om.forward(torch.from_numpy(images), params, training=True)
+        loss = lo([torch.from_numpy(y) for y in yt], outs)
+        loss.backward()
+        om.adam_step(params, state, lr=1e-4)
+        return float(loss)
+
+    one()                                   # warm-up (allocator, oneDNN primitive cache)
+    t0 = time.time()
+    one()
+    dt = time.time() - t0
+    return {"value": sample_batch / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 train step (fwd+loss+bwd+Adam) of the torch-CPU oracle at {size}x{size}, "
+                      f"batch {sample_batch}, after 1 warm-up step; {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=SIZE)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from multigriddet_amd import ops
+    from multigriddet_amd.engine import Network
+    from multigriddet_amd.train_step import TrainStep
+
+    net = Network(80, 3, dev, seed=0)
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast(net.params, 0)
+        net.refresh_packed()
+    ts = TrainStep(net, coco_anchors(), 80, (args.size, args.size), args.batch, lr=1e-4, world_size=world,
+                   loss_kwargs=dict(loss_option=2, loss_normalization=["batch"]))
+    images, boxes = synth_batch(rank, args.batch, args.size)
+    images, boxes = torch.from_numpy(images).to(dev), torch.from_numpy(boxes).to(dev)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        comp = ts.step(images, boxes)
+    barrier()
+    if not args.no_kernel_events:
+        ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        comp = ts.step(images, boxes)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.PROFILE
+    ops.PROFILE = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    loss = float(comp[7])
+
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+    ips = world * args.batch * args.steps / dt
+    roof = None
+    if prof:
+        fl = sum(p[2] for p in prof if p[3] == "gemm128")
+        ms = sum(p[0].elapsed_time(p[1]) for p in prof if p[3] == "gemm128")
+        n = sum(1 for p in prof if p[3] == "gemm128")
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "conv_gather_gemm_kernel<2,2,4,4>", "achieved": round(ach, 2),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "traffic": None, "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+                "share_of_step_time": round(ms / (dt * 1e3), 3)}
+    out = {
+        "metric": "images/sec (train step, 608x608, bs/GPU=16)", "value": round(ips, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Darknet53+FPN+DenseYOLO head, {args.size}x{args.size} bs={args.batch}/GPU, "
+                               f"train step (targets+fwd+MultiGridLoss+bwd+Adam), COCO-80 synthetic",
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": round(loss, 4),
+                   "train_tflops_per_gpu": round(ips / world * 3 * FLOP_PER_IMAGE_FWD * (args.size / 608) ** 2 / 1e12, 1)},
+        "roofline": roof,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.size)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,7 +107,7 @@ class Network:
             else:
                 cv.bias = self.params[cv.off_a:cv.off_a + C]
                 cv.dbias = self.grads[cv.off_a:cv.off_a + C]
-            cv.pk = None if cv.role == "stem" else ops.PackedConv(cv.cout, cv.cin, cv.k, cv.s, dev, need_dgrad=(i != 1) or True)
+            cv.pk = None if cv.role == "stem" else ops.PackedConv(cv.cout, cv.cin, cv.k, cv.s, dev, need_dgrad=True)
         self.training = True
         self.freeze_backbone = False
         self.freeze_all_but_pred = False
@@ -307,10 +307,6 @@ class Network:
         ops.bn_act_bwd(da, y, cv.scale, cv.shift, cv.smean, cv.sinv, cv.sums, cv.dgamma, cv.dbeta, dy, frozen=frozen)
         return dy
 
-    def _input_of(self, A, i):
-        """Activation tensor that layer i consumed in forward."""
-        return A["in"][i]
-
     def backward(self, douts, on_layer_done=None):
         """douts: three bf16 grads wrt the head outputs.  Accumulates into self.grads (zero it first).
         on_layer_done(i) is called when every gradient of layers >= i is final (DP bucket hook)."""
@@ -322,12 +318,13 @@ class Network:
         train_head_only = self.freeze_backbone
         pred_only = self.freeze_all_but_pred
 
-        def inp(i):
-            return self._fwd_inputs[i]
+        if "fin" not in A:
+            self._wire(A)
+        fin = A["fin"]
 
-        # rebuild the forward wiring (indices only)
-        if not hasattr(self, "_fwd_inputs"):
-            self._wire()
+        def inp(i):
+            return fin[i]
+
         head0 = BACKBONE_CONVS
         d_up = {}            # grads for lateral activations, keyed by scale
         d_skip = {}          # grads for the backbone taps
@@ -374,11 +371,8 @@ class Network:
                 du = self._scratch(A, f"du{sc}", (B, gh, gw, lat.cout))
                 skip_c = xin.shape[-1] - lat.cout
                 dsk = self._scratch(A, f"dskip{sc}", (B, 2 * gh, 2 * gw, skip_c))
-                if train_head_only:
-                    ops.upsample_concat_bwd(d_cat, du, dsk)
-                else:
-                    ops.upsample_concat_bwd(d_cat, du, dsk)
-                    d_skip[sc - 1] = dsk
+                ops.upsample_concat_bwd(d_cat, du, dsk)
+                d_skip[sc - 1] = dsk
                 d_up[sc - 1] = du
             elif not train_head_only:
                 g_f1 = ops.conv_dgrad(dy1, Lr[c1].pk, hw[c1], out=self._scratch(A, "g5", acts[BACKBONE_CONVS - 1].shape))
@@ -426,9 +420,8 @@ class Network:
         if on_layer_done:
             on_layer_done(0)
 
-    def _wire(self):
-        """Forward input activation of each backbone conv (index into A['a']), resolved lazily."""
-        A = self._last
+    def _wire(self, A):
+        """Forward input activation of each backbone conv, per arena."""
         acts = A["a"]
         fin = {}
         i = 1
@@ -443,8 +436,7 @@ class Network:
                 x = i + 1
                 i += 2
             prev = x
-        self._fwd_inputs = fin
-        self._wired_for = id(A)
+        A["fin"] = fin
 
     def zero_grad(self):
         self.grads.zero_()

@@ -15,6 +15,22 @@ BN_EPS = 1e-3          # Keras BatchNormalization default (reference models/laye
 BN_MOMENTUM = 0.99
 LEAKY_SLOPE = 0.1
 STATS_REPLICAS = 16
+# bench.py sets this to a list to bracket every gather-GEMM launch with HIP events on the launch
+# stream: entries are (start_event, end_event, algorithmic_flops, kernel_variant).
+PROFILE = None
+
+
+def _launch_gemm(d, what):
+    lib = L.load()
+    if PROFILE is None:
+        L.check(lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), what)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), what)
+    e1.record()
+    variant = "gemm128" if d.Co_pad % 128 == 0 else ("gemm64" if d.Co_pad % 64 == 0 else "gemm32")
+    PROFILE.append((e0, e1, 2.0 * d.N * d.Hg * d.Wg * d.ntaps * d.Ci * d.Co, variant))
 
 
 def _ru(x, m):
@@ -109,7 +125,7 @@ def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False):
     dh, dw = taps_fwd(pk.k)
     d = _desc(x, pk.fwd, out, N, H, W, Ci, Ho, Wo, Ho, Wo, pk.co, pk.s, 1, (0, 0), dh, dw, pk.fwd_kpad,
               pk.fwd_copad, bias=bias, stats=stats, dst_f32=out_f32)
-    L.check(L.load().mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), "conv_fwd")
+    _launch_gemm(d, "conv_fwd")
     return out
 
 
@@ -125,12 +141,12 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None):
         img, kp, cp, _, _ = pk.dgrad[0]
         dh, dw = taps_fwd(pk.k)
         d = _desc(dy, img, out, N, Ho, Wo, Co, H, W, H, W, pk.ci, 1, 1, (0, 0), dh, dw, kp, cp, addend=addend)
-        L.check(lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), "conv_dgrad")
+        _launch_gemm(d, "conv_dgrad")
     else:
         for img, kp, cp, _, (ph, pw, tp) in pk.dgrad:
             d = _desc(dy, img, out, N, Ho, Wo, Co, H // 2, W // 2, H, W, pk.ci, 1, 2, (ph, pw),
                       [t[0] for t in tp], [t[1] for t in tp], kp, cp, addend=addend)
-            L.check(lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), "conv_dgrad_s2")
+            _launch_gemm(d, "conv_dgrad_s2")
     return out
 
 

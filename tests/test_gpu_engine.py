@@ -1,0 +1,143 @@
+"""GPU: the 69-conv graph executor (forward, backward, one optimiser step) against the torch-CPU oracle
+with identical weights.  The product computes convs in bf16 MFMA with fp32 accumulation, the oracle
+in fp32, so bounds are relative-L2 / cosine (1e-4 is demanded of the loss and box kernels on equal
+fp32 inputs - tests/test_gpu_kernels.py - not end to end through 69 bf16 convs)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import coco_anchors
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    assert torch.cuda.is_available()
+    from multigriddet_amd.engine import Network
+    from oracle import model as om
+    net = Network(80, 3, "cuda:0", seed=0)
+    params = om.init_params(seed=3)
+    rng = np.random.default_rng(4)
+    for p in params:                      # non-trivial BN affine / bias so that their gradients matter
+        if "gamma" in p:
+            p["gamma"] = rng.uniform(0.7, 1.3, p["gamma"].shape).astype(np.float32)
+            p["beta"] = rng.normal(0, 0.1, p["beta"].shape).astype(np.float32)
+        else:
+            p["bias"] = rng.normal(0, 0.1, p["bias"].shape).astype(np.float32)
+    net.load_keras_style(params)
+    return net, params
+
+
+def test_param_count_and_layout(setup):
+    net, params = setup
+    from oracle import model as om
+    assert len(net.layers) == 69
+    assert net.count_params() == om.count_params(params) == 44996904
+    assert net.n_params == 44954760                     # trainable (README "~45M")
+    back = net.export_keras_style()
+    for a, b in zip(back, params):
+        for k in b:
+            np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_forward_backward_vs_oracle(setup):
+    net, params = setup
+    from multigriddet_amd import ops
+    from oracle import model as om
+    from oracle.loss import MultiGridLossOracle
+    from oracle import targets as ot
+    B, S = 4, 128
+    rng = np.random.default_rng(0)
+    img = rng.random((B, S, S, 3), dtype=np.float32)
+    tb = np.zeros((B, 10, 5), np.float32)
+    for b in range(B):
+        for t in range(3):
+            w, h = rng.uniform(10, 70, 2)
+            cx, cy = rng.uniform(w / 2, S - w / 2), rng.uniform(h / 2, S - h / 2)
+            tb[b, t] = [cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, rng.integers(0, 80)]
+    yt = ot.tf_preprocess_true_boxes(tb, (S, S), coco_anchors(), 80)
+
+    # ---- oracle: fp32 torch CPU, training-mode BN
+    tp = om.torch_params(params, requires_grad=True)
+    outs_ref = om.forward(torch.from_numpy(img), tp, training=True)
+    lo = MultiGridLossOracle(coco_anchors(), 80, (S, S))
+    loss_ref = lo([torch.from_numpy(y) for y in yt], outs_ref)
+    loss_ref.backward()
+
+    # ---- product
+    net.training = True
+    net.freeze_backbone = False
+    outs = net.forward(torch.from_numpy(img).cuda())
+    torch.cuda.synchronize()
+    for l in range(3):
+        r = rel_l2(outs[l].cpu().numpy(), outs_ref[l].detach().numpy())
+        assert r < 0.05, f"head {l} rel-L2 {r}"
+    grids = [(S // 32,) * 2, (S // 16,) * 2, (S // 8,) * 2]
+    cfg = ops.make_loss_cfg(coco_anchors(), 80, (S, S), B, grids)
+    run = ops.LossRunner(cfg, net.device)
+    douts = [torch.empty_like(o, dtype=torch.bfloat16) for o in outs]
+    comp = run.run([torch.from_numpy(y).cuda() for y in yt], outs, grad_bf16=douts)
+    net.zero_grad()
+    net.backward(douts)
+    torch.cuda.synchronize()
+    assert abs(float(comp[7]) - float(loss_ref)) < 0.03 * abs(float(loss_ref))
+    g = net.grads.cpu().numpy()
+    worst = 1.0
+    for cv, p in zip(net.layers, tp):
+        gw = g[cv.off_w:cv.off_w + cv.cout * cv.T * cv.cin].reshape(cv.cout, cv.k, cv.k, cv.cin)
+        ref = p["kernel"].grad.numpy().transpose(3, 0, 1, 2)
+        c = cosine(gw, ref)
+        worst = min(worst, c)
+        assert c > 0.97, f"layer {cv.idx} ({cv.role}) kernel-grad cosine {c}"
+        if cv.bn:
+            assert cosine(g[cv.off_a:cv.off_a + cv.cout], p["gamma"].grad.numpy()) > 0.95, f"layer {cv.idx} dgamma"
+            assert cosine(g[cv.off_b:cv.off_b + cv.cout], p["beta"].grad.numpy()) > 0.95, f"layer {cv.idx} dbeta"
+        else:
+            assert cosine(g[cv.off_a:cv.off_a + cv.cout], p["bias"].grad.numpy()) > 0.99, f"layer {cv.idx} dbias"
+    print("worst kernel-grad cosine", worst)
+
+
+def test_inference_mode_and_frozen_backbone(setup):
+    net, params = setup
+    from oracle import model as om
+    B, S = 2, 96
+    img = np.random.default_rng(1).random((B, S, S, 3), dtype=np.float32)
+    tp = om.torch_params(params)
+    ref = om.forward(torch.from_numpy(img), tp, training=False)
+    net.training = False
+    outs = net.forward(torch.from_numpy(img).cuda())
+    torch.cuda.synchronize()
+    for l in range(3):
+        assert rel_l2(outs[l].cpu().numpy(), ref[l].numpy()) < 0.05
+    net.training = True
+
+
+def test_train_step_reduces_loss(setup):
+    net, _ = setup
+    from multigriddet_amd.train_step import TrainStep
+    net.reset_parameters(0)
+    B, S = 4, 128
+    rng = np.random.default_rng(5)
+    img = torch.from_numpy(rng.random((B, S, S, 3), dtype=np.float32)).cuda()
+    tb = np.zeros((B, 10, 5), np.float32)
+    for b in range(B):
+        tb[b, 0] = [20, 30, 90, 100, 3]
+        tb[b, 1] = [60, 10, 120, 50, 7]
+    ts = TrainStep(net, coco_anchors(), 80, (S, S), B, lr=1e-3)
+    losses = []
+    boxes = torch.from_numpy(tb).cuda()
+    for _ in range(12):
+        losses.append(float(ts.step(img, boxes)[7]))
+    assert np.isfinite(losses).all()
+    assert losses[-1] < 0.7 * losses[0], losses
