@@ -52,33 +52,49 @@ def synth_batch(rank, batch, size, max_boxes=100):
     return images, boxes
 
 
-def cpu_baseline(size, sample_batch=2):
-    """Oracle train step (torch-CPU fp32 conv/BN/autograd + restated loss/targets + Adam) on the host."""
+def host_cores():
+    """Cores this process may really use: min(affinity, cgroup cpu quota).  os.cpu_count() on a
+    shared box reports every core of the host and oversubscribing them makes torch-CPU crawl."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(size):
+    """Oracle train step (torch-CPU fp32 conv/BN/autograd + restated loss/targets + Adam) on the host:
+    bounded sample = ONE image at the benchmark resolution, one step, after a tiny warm-up step."""
     from oracle import model as om
     from oracle.loss import MultiGridLossOracle
     from oracle import targets as ot
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
-    images, boxes = synth_batch(0, sample_batch, size)
     params = om.torch_params(om.init_params(0), requires_grad=True)
-    lo = MultiGridLossOracle(coco_anchors(), 80, (size, size))
     state = {}
 
-    def one():
-        yt = ot.tf_preprocess_true_boxes(boxes, (size, size), coco_anchors(), 80)
+    def one(sz, batch):
+        images, boxes = synth_batch(0, batch, sz)
+        lo = MultiGridLossOracle(coco_anchors(), 80, (sz, sz))
+        yt = ot.tf_preprocess_true_boxes(boxes, (sz, sz), coco_anchors(), 80)
         outs = om.forward(torch.from_numpy(images), params, training=True)
         loss = lo([torch.from_numpy(y) for y in yt], outs)
         loss.backward()
         om.adam_step(params, state, lr=1e-4)
-        return float(loss)
+        return float(loss.detach())
 
-    one()                                   # warm-up (allocator, oneDNN primitive cache)
+    print("[bench] cpu_baseline warm-up ...", file=sys.stderr, flush=True)
+    one(128, 1)
+    print("[bench] cpu_baseline timed step ...", file=sys.stderr, flush=True)
     t0 = time.time()
-    one()
+    one(size, 1)
     dt = time.time() - t0
-    return {"value": sample_batch / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 train step (fwd+loss+bwd+Adam) of the torch-CPU oracle at {size}x{size}, "
-                      f"batch {sample_batch}, after 1 warm-up step; {dt:.2f} s"}
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 train step (targets+fwd+loss+bwd+Adam) of the torch-CPU oracle at {size}x{size}, "
+                      f"batch 1, {cores} threads, after a 128x128 warm-up step; {dt:.2f} s"}
 
 
 def main():

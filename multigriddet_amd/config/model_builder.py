@@ -1,0 +1,95 @@
+"""YAML -> builder kwargs (reference multigriddet/config/model_builder.py:22-330), same key names, same
+precedence (training.learning_rate > optimizer.learning_rate > 1e-3), same errors."""
+import os
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from ..models import Optimizer, build_multigriddet_darknet, build_multigriddet_darknet_train
+
+_LOSS_KEYS = {"coord_scale": 1.0, "object_scale": 1.0, "no_object_scale": 1.0, "class_scale": 1.0, "anchor_scale": 1.0,
+              "use_iou_aware_objectness": False, "iou_objectness_power": 1.0, "iou_objectness_ratio": 1.0,
+              "trainable_nms_weight": 0.0, "trainable_nms_power": 2.0, "use_consensus_loss": False,
+              "consensus_kernel_size": 3, "consensus_iou_power": 1.5, "consensus_min_iou": 1e-3,
+              "consensus_coord_scale": 0.5, "consensus_obj_scale": 0.5, "consensus_class_scale": 0.3,
+              "consensus_stop_gradient": True, "consensus_center_tolerance": 1e-4}
+
+
+def create_optimizer_from_config(config: Dict[str, Any]) -> Optimizer:
+    oc, tc = config.get("optimizer", {}), config.get("training", {})
+    kind = oc.get("type", "adam").lower()
+    lr = tc["learning_rate"] if "learning_rate" in tc else oc.get("learning_rate", 0.001)
+    if kind == "adamw":
+        return Optimizer("adamw", lr, weight_decay=oc.get("weight_decay", oc.get("decay", 0.0005)),
+                         beta_1=oc.get("beta_1", 0.9), beta_2=oc.get("beta_2", 0.999), epsilon=oc.get("epsilon", 1e-7))
+    if kind == "sgd":
+        return Optimizer("sgd", lr, momentum=oc.get("momentum", 0.937), nesterov=oc.get("nesterov", False))
+    return Optimizer("adam", lr, beta_1=oc.get("beta_1", 0.9), beta_2=oc.get("beta_2", 0.999),
+                     epsilon=oc.get("epsilon", 1e-7))
+
+
+def build_model_from_config(config, for_training=False, anchors: List = None, weights_path: Optional[str] = None,
+                            backbone_weights_path: Optional[str] = None, world_size: int = 1):
+    mc = config["model"]
+    if mc["type"] == "custom":
+        raise NotImplementedError("Custom model composition not yet implemented. Use preset models.")
+    if mc["type"] != "preset":
+        raise ValueError(f"Unknown model type: {mc['type']}")
+    preset = mc["preset"]
+    arch, num_classes, input_shape = preset["architecture"], preset["num_classes"], tuple(preset["input_shape"])
+    if arch not in ("multigriddet_darknet", "multigriddet_resnet"):
+        raise ValueError(f"Unknown architecture: {arch}")
+    if not for_training:
+        return build_multigriddet_darknet(input_shape=input_shape, num_classes=num_classes,
+                                          num_anchors_per_head=[3, 3, 3],
+                                          weights_path=backbone_weights_path or weights_path)[0]
+    tc = config.get("training", {})
+    loss_scales = {}
+    if tc.get("loss"):
+        loss_scales = {k: tc["loss"].get(k, d) for k, d in _LOSS_KEYS.items()}
+    if tc.get("loss_normalization") is not None:
+        loss_scales["loss_normalization"] = tc["loss_normalization"]
+    cw = tc.get("class_weights")
+    if isinstance(cw, (list, np.ndarray)):
+        cw = np.array(cw, dtype=np.float32)
+        if len(cw) != num_classes:
+            raise ValueError(f"class_weights length ({len(cw)}) must match num_classes ({num_classes})")
+        loss_scales["class_weights"] = cw
+    elif isinstance(cw, str) and cw.lower() == "auto":
+        from ..utils.anchors import compute_class_weights
+        ann = config.get("data", {}).get("train_annotation")
+        if ann:
+            loss_scales["class_weights"] = compute_class_weights(ann, num_classes, tc.get("class_weights_method", "balanced"))
+    freeze_level = tc.get("freeze_level", 1) if tc.get("transfer_epochs", 0) > 0 else 0
+    return build_multigriddet_darknet_train(
+        anchors=anchors, input_shape=input_shape, num_classes=num_classes, weights_path=weights_path,
+        backbone_weights_path=backbone_weights_path, freeze_level=freeze_level,
+        optimizer=create_optimizer_from_config(config), loss_option=tc.get("loss_option", 2), world_size=world_size,
+        **loss_scales)[0]
+
+
+def build_model_for_training(config, anchors=None, weights_path=None, backbone_weights_path=None, world_size=1):
+    return build_model_from_config(config, True, anchors, weights_path, backbone_weights_path, world_size)
+
+
+def build_model_for_inference(config, weights_path=None):
+    model = build_model_from_config(config, for_training=False)
+    weights_path = weights_path or config.get("weights_path")
+    if weights_path and (os.path.exists(weights_path) or os.path.exists(weights_path + ".npz")):
+        model.load_weights(weights_path)
+        print(f"Loaded weights from: {weights_path}")
+    elif weights_path:
+        print(f"Warning: Weights file not found: {weights_path}")
+    else:
+        print("Warning: No weights path specified")
+    return model
+
+
+def get_model_info(config):
+    mc = config["model"]
+    info = {"name": mc.get("name", "unknown"), "type": mc.get("type", "preset"), "architecture": None,
+            "num_classes": None, "input_shape": None, "num_anchors_per_head": [3, 3, 3]}
+    if mc["type"] == "preset":
+        p = mc["preset"]
+        info.update(architecture=p["architecture"], num_classes=p["num_classes"], input_shape=tuple(p["input_shape"]))
+    return info

@@ -1,0 +1,174 @@
+"""Target builders and the batch generator with the reference's signatures, on gfx950.
+
+ * tf_preprocess_true_boxes(true_boxes, input_shape, anchors, num_classes, multi_anchor_assign, grid_shapes)
+   -> [y_true]      (reference multigriddet/data/generators.py:2697-2703; default trainer path)
+ * preprocess_true_boxes(true_boxes, input_shape, anchors, num_classes, multi_anchor_assign, grid_shapes=None,
+   iou_thresh=0.2)  (reference :3393; asserts class id < num_classes like the reference :3409)
+ * MultiGridDataGenerator(annotation_lines, batch_size, input_shape, anchors, num_classes, ...)
+   (reference :1403-1419): len(), [i] -> ((images, y0, y1, y2), zeros(B)), on_epoch_end().
+   Host side it only parses annotation lines and letterboxes images (PIL); Mosaic / MixUp / GridMask
+   and the target encoding run on the device.  JPEG decode and the PIL/imgaug colour pipeline of the
+   reference are host I/O outside the accelerated path and are not reproduced.
+"""
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+from . import augment as aug
+
+
+def _boxes_dev(true_boxes):
+    if isinstance(true_boxes, torch.Tensor):
+        return true_boxes.to("cuda", torch.float32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(true_boxes, np.float32)).cuda()
+
+
+def tf_preprocess_true_boxes(true_boxes, input_shape, anchors, num_classes, multi_anchor_assign=False,
+                             grid_shapes=None, debug_aug_pipeline=False):
+    tb = _boxes_dev(true_boxes)
+    if tb.dim() != 3 or tb.shape[2] != 5:
+        raise ValueError("true_boxes must be rank 3: (batch, max_boxes, 5)")
+    return ops.build_targets(tb, input_shape, anchors, num_classes, grid_shapes, mode=0)
+
+
+def preprocess_true_boxes(true_boxes, input_shape, anchors, num_classes, multi_anchor_assign=False, grid_shapes=None,
+                          iou_thresh=0.2):
+    tb = _boxes_dev(true_boxes)
+    assert bool((tb[..., 4] < num_classes).all()), "class id must be less than num_classes"
+    return ops.build_targets(tb, input_shape, anchors, num_classes, grid_shapes, mode=1)
+
+
+def get_multiscale_list():
+    """reference data/utils.py:15-29: 320 ... 672 step 32."""
+    return [(s, s) for s in range(320, 672 + 1, 32)]
+
+
+def load_annotation_lines(path, shuffle=False):
+    with open(path) as f:
+        lines = [l.strip() for l in f if l.strip()]
+    if shuffle:
+        np.random.shuffle(lines)
+    return lines
+
+
+def parse_annotation_line(line):
+    """'path x1,y1,x2,y2,cls ...' (reference generators.py:2425-2429) -> (path, boxes [n,5])."""
+    parts = line.split()
+    boxes = [list(map(float, p.split(",")))[:5] for p in parts[1:] if p]
+    boxes = [b + [0.0] * (5 - len(b)) for b in boxes]
+    boxes = np.array([b for b in boxes if any(v != 0 for v in b)], np.float32).reshape(-1, 5)
+    return parts[0], boxes
+
+
+def letterbox(image, boxes, target_hw, fill=0):
+    """Aspect-preserving resize (bicubic) + centred pad; boxes mapped along.  Training pads with zeros
+    (tf.image.pad_to_bounding_box, reference generators.py:167-209); inference pads with 128
+    (utils/preprocessing.py:46) - pass fill accordingly."""
+    from PIL import Image
+    th, tw = target_hw
+    w, h = image.size
+    r = min(tw / w, th / h)
+    nw, nh = max(1, int(round(w * r))), max(1, int(round(h * r)))
+    ox, oy = (tw - nw) // 2, (th - nh) // 2
+    canvas = Image.new("RGB", (tw, th), (fill, fill, fill))
+    canvas.paste(image.resize((nw, nh), Image.BICUBIC), (ox, oy))
+    out = boxes.copy()
+    if len(out):
+        out[:, [0, 2]] = out[:, [0, 2]] * r + ox
+        out[:, [1, 3]] = out[:, [1, 3]] * r + oy
+    return np.asarray(canvas, np.float32), out
+
+
+class MultiGridDataGenerator:
+    def __init__(self, annotation_lines: List[str], batch_size: int, input_shape: Tuple[int, int],
+                 anchors: List[np.ndarray], num_classes: int, augment: bool = True,
+                 enhance_augment: Optional[str] = None, rescale_interval: int = -1,
+                 multi_anchor_assign: bool = False, shuffle: bool = True, prefetch_factor: int = 2,
+                 num_workers: int = 8, mosaic_prob: float = 0.3, mixup_prob: float = 0.1,
+                 max_boxes_per_image: int = 100, seed: int = 0, gridmask_prob: float = 0.1, **kwargs):
+        self.annotation_lines = list(annotation_lines)
+        self.batch_size = batch_size
+        self.input_shape = tuple(input_shape)
+        self.anchors = [np.asarray(a, np.float32) for a in anchors]
+        self.num_classes = num_classes
+        self.augment, self.enhance_augment = augment, enhance_augment
+        self.rescale_interval, self.multi_anchor_assign, self.shuffle = rescale_interval, multi_anchor_assign, shuffle
+        self.mosaic_prob, self.mixup_prob, self.gridmask_prob = mosaic_prob, mixup_prob, gridmask_prob
+        self.max_boxes_per_image = max_boxes_per_image
+        self.indexes = np.arange(len(self.annotation_lines))
+        self.num_layers = len(anchors)
+        self.grid_shapes = [(self.input_shape[0] // s, self.input_shape[1] // s) for s in (32, 16, 8, 4, 2)][:self.num_layers]
+        self.rng = np.random.default_rng(seed)
+        if shuffle:
+            self.rng.shuffle(self.indexes)
+
+    def _calculate_expansion_factor(self) -> int:
+        """reference generators.py:1492-1517: 8x (Mosaic+MixUp), 4x, 2x, 1x."""
+        mosaic = (self.enhance_augment == "mosaic") and self.mosaic_prob > 0.0
+        mix = self.mixup_prob > 0.0
+        return 8 if (mosaic and mix) else 4 if mosaic else 2 if mix else 1
+
+    def __len__(self):
+        return max(1, int(np.ceil(len(self.annotation_lines) / float(self.batch_size))))
+
+    def on_epoch_end(self):
+        if self.shuffle:
+            self.rng.shuffle(self.indexes)
+
+    def _load(self, line):
+        from PIL import Image
+        path, boxes = parse_annotation_line(line)
+        img = Image.open(path).convert("RGB")
+        return letterbox(img, boxes, self.input_shape, fill=0)
+
+    def load_batch(self, i):
+        """Host part: returns (images uint8-range fp32 [B,H,W,3], boxes [B, capacity, 5])."""
+        idx = self.indexes[i * self.batch_size:(i + 1) * self.batch_size]
+        if len(idx) < self.batch_size:
+            idx = np.concatenate([idx, self.indexes[:self.batch_size - len(idx)]])
+        cap = self.max_boxes_per_image * (self._calculate_expansion_factor() if self.augment else 1)
+        H, W = self.input_shape
+        images = np.zeros((self.batch_size, H, W, 3), np.float32)
+        boxes = np.zeros((self.batch_size, cap, 5), np.float32)
+        for j, k in enumerate(idx):
+            im, bx = self._load(self.annotation_lines[k])
+            if len(bx) > self.max_boxes_per_image:
+                raise RuntimeError(f"image has {len(bx)} boxes, capacity {self.max_boxes_per_image}")
+            images[j] = im
+            boxes[j, :len(bx)] = bx
+        return images, boxes
+
+    def device_batch(self, images, boxes):
+        """Device part: batch augmentation (uint8-range) -> /255 -> targets.  images/boxes numpy or CUDA."""
+        img = torch.as_tensor(images).cuda().float().contiguous()
+        bx = torch.as_tensor(boxes).cuda().float().contiguous()
+        B, S = img.shape[0], img.shape[1]
+        if self.augment and img.shape[1] == img.shape[2]:
+            if self.enhance_augment == "mosaic" and B >= 4 and self.rng.uniform() < self.mosaic_prob:
+                img, bx = aug.mosaic(img, bx, *aug.draw_mosaic(self.rng, B, S))
+            if self.mixup_prob > 0 and B >= 2 and self.rng.uniform() < self.mixup_prob:
+                img, bx = aug.mixup(img, bx, *aug.draw_mixup(self.rng, B))
+            if self.gridmask_prob > 0:
+                apply, par = aug.draw_gridmask(self.rng, B, S, self.gridmask_prob)
+                if apply.any():
+                    aug.gridmask(img, bx, apply, par)
+        img = img / 255.0
+        y = tf_preprocess_true_boxes(bx, self.input_shape, self.anchors, self.num_classes, self.multi_anchor_assign,
+                                     self.grid_shapes)
+        return img, bx, y
+
+    def __getitem__(self, i):
+        images, boxes = self.load_batch(i)
+        img, _, y = self.device_batch(images, boxes)
+        return (img, *y), torch.zeros(self.batch_size, device=img.device)
+
+    def build_tf_dataset(self, *args, **kwargs):
+        """The reference returns a tf.data.Dataset (:1766); here the generator itself is the iterable."""
+        return self
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]

@@ -1,0 +1,68 @@
+"""MultiGridDecoder with the reference's interface, running decode + NMS on gfx950.
+
+Mirrors `MultiGridDecoder(anchors, num_classes, input_shape, rescore_confidence, use_softmax)` and
+`.postprocess(outputs, image_shape, model_image_size, max_boxes, confidence, nms_threshold, use_iol,
+nms_method, use_wbf, return_xyxy) -> (boxes int32 (N,4) xyxy, classes int32 (N,), scores (N,))`
+(reference multigriddet/postprocess/multigrid_decode.py:25-30, 347-395); empty results are three
+empty arrays (:274).  `postprocess_batch` is the batched device entry the inference/eval loops use
+(no per-image device->host copy before NMS, unlike evaluator.py:257).
+Differences, stated: nms_method 'soft' and use_wbf are host-side algorithms in the reference and are not
+on the device path (NotImplementedError); an unknown nms_method raises NotImplementedError exactly as
+the reference's abstract NMS does (multigrid_decode.py:297).
+"""
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+class MultiGridDecoder:
+    def __init__(self, anchors: List[np.ndarray], num_classes: int, input_shape: Tuple[int, int] = (608, 608),
+                 rescore_confidence: bool = True, use_softmax: bool = True):
+        self.anchors = [np.asarray(a, np.float32) for a in anchors]
+        self.num_classes = num_classes
+        self.input_shape = tuple(input_shape)
+        self.rescore_confidence = rescore_confidence
+        self.use_softmax = use_softmax
+        self.num_layers = len(anchors)
+
+    def _dev(self, t):
+        if isinstance(t, torch.Tensor):
+            return t.to("cuda", torch.float32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(t, np.float32)).cuda()
+
+    def postprocess_batch(self, outputs: Sequence, image_shapes, max_boxes=100, confidence=0.1, nms_threshold=0.5,
+                          nms_method="diou", return_xyxy=True):
+        """outputs: L tensors [B,g,g,F]; image_shapes: [B,2] (h,w).  Returns device tensors
+        (boxes [B,max_boxes,4], scores [B,max_boxes], classes [B,max_boxes], count [B])."""
+        if len(outputs) != self.num_layers:
+            raise ValueError(f"Expected {self.num_layers} predictions, got {len(outputs)}")
+        if nms_method not in ops.NMS_METHODS:
+            raise NotImplementedError("Subclasses must implement apply_nms method")
+        outs = [self._dev(o) for o in outputs]
+        B = outs[0].shape[0]
+        grids = [(int(o.shape[1]), int(o.shape[2])) for o in outs]
+        ihw = torch.as_tensor(np.asarray(image_shapes, np.float32).reshape(B, 2)).cuda()
+        cfg = ops.make_decode_cfg(self.anchors, self.num_classes, self.input_shape, B, grids, confidence,
+                                  use_softmax=self.use_softmax, rescore=self.rescore_confidence)
+        b, s, c, n = ops.decode(cfg, outs, ihw)
+        return ops.nms(b, s, c, n, ihw, method=nms_method, threshold=nms_threshold, max_boxes=max_boxes,
+                       return_xyxy=return_xyxy)
+
+    def postprocess(self, multigriddet_outputs, image_shape, model_image_size, max_boxes: int = 100,
+                    confidence: float = 0.1, nms_threshold: float = 0.5, use_iol: bool = True,
+                    nms_method: str = "diou", use_wbf: bool = False, return_xyxy: bool = True):
+        if use_wbf:
+            raise NotImplementedError("WeightedBoxesFusion is not on the gfx950 path")
+        if nms_method == "soft":
+            raise NotImplementedError("SoftNMS is not on the gfx950 path")
+        if tuple(model_image_size) != tuple(self.input_shape):
+            self.input_shape = tuple(model_image_size)
+        ob, osc, ocl, ocn = self.postprocess_batch(multigriddet_outputs, [image_shape], max_boxes, confidence,
+                                                   nms_threshold, nms_method, return_xyxy)
+        k = int(ocn[0])
+        if k == 0:
+            return np.array([]), np.array([]), np.array([])
+        return ob[0, :k].cpu().numpy(), ocl[0, :k].cpu().numpy().astype("int32"), osc[0, :k].cpu().numpy()

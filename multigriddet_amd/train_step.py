@@ -10,6 +10,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .dp import GradBuckets
 
 
 class TrainStep:
@@ -35,39 +36,7 @@ class TrainStep:
         self._loss = {}
         self._douts = {}
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
-        self._make_buckets(bucket_mb)
-
-    # ------------------------------------------------------------------ DP buckets
-    def _make_buckets(self, bucket_mb):
-        """Contiguous slices of the flat gradient, built from the last layer backwards (the order in
-        which backward finalises them), ~bucket_mb each."""
-        lim = int(bucket_mb * 1e6 / 4)
-        self.buckets = []          # (first_layer_idx, begin, end)
-        end = self.net.n_params
-        begin = end
-        for cv in reversed(self.net.layers):
-            begin = cv.off_w
-            if end - begin >= lim or cv.idx == 0:
-                self.buckets.append((cv.idx, begin, end))
-                end = begin
-        self._next_bucket = 0
-        self._works = []
-
-    def _on_layer_done(self, i):
-        if self.world <= 1:
-            return
-        lo = self.net.trainable_range()[0]
-        while self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= i:
-            first, b, e = self.buckets[self._next_bucket]
-            self._next_bucket += 1
-            b = max(b, lo)
-            if e <= b:
-                continue
-            ev = torch.cuda.Event()
-            ev.record()
-            self.comm_stream.wait_event(ev)
-            with torch.cuda.stream(self.comm_stream):
-                self._works.append(dist.all_reduce(self.net.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
+        self.dp = GradBuckets(net.grads, [cv.off_w for cv in net.layers], world_size, bucket_mb, self.comm_stream)
 
     # ------------------------------------------------------------------ helpers
     def _grids(self, H, W):
@@ -96,13 +65,13 @@ class TrainStep:
         net.zero_grad()
         runner, douts = self._loss_runner(B, H, W)
         comp = runner.run(y_true, outs, grad_bf16=douts)
-        self._next_bucket = 0
-        self._works = []
-        net.backward(douts, on_layer_done=self._on_layer_done if self.world > 1 else None)
         if self.world > 1:
-            self._on_layer_done(0)
-            for w in self._works:
-                w.wait()          # makes the compute stream wait for the collective
+            rng_ = net.trainable_range()
+            self.dp.reset(lo=rng_[0] if rng_ else 0)
+            net.backward(douts, on_layer_done=self.dp.on_layer_done)
+            self.dp.finish()      # makes the compute stream wait for the collectives
+        else:
+            net.backward(douts)
         self.apply_optimizer()
         return comp
 

@@ -77,9 +77,18 @@ def init_params(seed=0, num_classes=80, num_anchors=3):
     return params
 
 
-def conv_bn_leaky(x, p, sp, training, stats_out=None):
-    """x: NCHW torch tensor. Returns activated output."""
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def conv_bn_leaky(x, p, sp, training, stats_out=None, emulate_bf16=False, residual=None):
+    """x: NCHW torch tensor. Returns activated output (+ residual).
+    emulate_bf16=True rounds the weights, the raw conv output and the activation to bf16 at the points
+    where the gfx950 path stores bf16 (fp32 accumulation in between), so that the comparison with the
+    product isolates logic errors from bf16 storage noise."""
     w = p["kernel"].permute(3, 2, 0, 1)                     # (kh,kw,cin,cout) -> OIHW
+    if emulate_bf16 and sp["cin"] != 3:
+        w = _bf16(w)
     if sp["s"] == 2:
         x = F.pad(x, (1, 0, 1, 0))                            # left, right, top, bottom: top/left only
         y = F.conv2d(x, w, stride=2)
@@ -87,6 +96,8 @@ def conv_bn_leaky(x, p, sp, training, stats_out=None):
         y = F.conv2d(x, w, padding=sp["k"] // 2)
     if not sp["bn"]:
         return y + p["bias"].view(1, -1, 1, 1)
+    if emulate_bf16:
+        y = _bf16(y)
     if training:
         mean = y.mean(dim=(0, 2, 3))
         var = y.var(dim=(0, 2, 3), unbiased=False)
@@ -96,17 +107,25 @@ def conv_bn_leaky(x, p, sp, training, stats_out=None):
         mean, var = p["moving_mean"], p["moving_var"]
     yn = (y - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + BN_EPS)
     yn = yn * p["gamma"].view(1, -1, 1, 1) + p["beta"].view(1, -1, 1, 1)
-    return F.leaky_relu(yn, LEAKY)
+    a = F.leaky_relu(yn, LEAKY)
+    if residual is not None:
+        a = a + residual
+    return _bf16(a) if emulate_bf16 else a
 
 
-def forward(images_nhwc, params, training=True, stats_out=None, taps_out=None):
-    """images: [B,H,W,3] float in [0,1].  Returns the three raw head tensors, NHWC."""
+def forward(images_nhwc, params, training=True, stats_out=None, taps_out=None, acts_out=None, emulate_bf16=False):
+    """images: [B,H,W,3] float in [0,1].  Returns the three raw head tensors, NHWC.
+    acts_out (optional list) receives every conv's output tensor (NCHW) in graph order; for the second
+    conv of a residual block the entry is the block output (after the Add)."""
     specs = layer_specs()
     it = iter(zip(specs, params))
 
-    def nxt(x):
+    def nxt(x, residual=None):
         sp, p = next(it)
-        return conv_bn_leaky(x, p, sp, training, stats_out)
+        y = conv_bn_leaky(x, p, sp, training, stats_out, emulate_bf16, residual)
+        if acts_out is not None:
+            acts_out.append(y)
+        return y
 
     x = images_nhwc.permute(0, 3, 1, 2)
     x = nxt(x)
@@ -114,8 +133,7 @@ def forward(images_nhwc, params, training=True, stats_out=None, taps_out=None):
     for f, n in ((64, 1), (128, 2), (256, 8), (512, 8), (1024, 4)):
         x = nxt(x)
         for _ in range(n):
-            y = nxt(nxt(x))
-            x = x + y
+            x = nxt(nxt(x), residual=x)
         feats[f] = x
     f1, f2, f3 = feats[1024], feats[512], feats[256]
     if taps_out is not None:

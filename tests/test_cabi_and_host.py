@@ -1,0 +1,92 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mgd_hip.h declares; host-side logic
+(tap tables, padding rules, bucket tiling, layer specs) is consistent.  No compute calls."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _build_if_needed():
+    from multigriddet_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib
+
+
+def test_header_symbols_exported():
+    _lib = _build_if_needed()
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "mgd_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(mgd_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(names) == sorted(_lib.EXPORTS)
+    assert lib.mgd_version() >= 1
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from multigriddet_amd import _lib
+    from multigriddet_amd.engine import Network
+    with pytest.raises(_lib.MgdError):
+        Network(80, 3, "cuda:0")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "multigriddet_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_layer_specs_match_oracle_graph():
+    from multigriddet_amd.engine import conv_specs
+    from oracle import model as om
+    a, b = conv_specs(), om.layer_specs()
+    assert len(a) == len(b) == 69
+    for x, y in zip(a, b):
+        assert (x["cin"], x["cout"], x["k"], x["s"], x["bn"]) == (y["cin"], y["cout"], y["k"], y["s"], y["bn"])
+
+
+def test_stride2_dgrad_parity_classes_cover_all_taps():
+    from multigriddet_amd.ops import taps_dgrad_s2
+    seen = []
+    for ph in range(2):
+        for pw in range(2):
+            for dh, dw, t in taps_dgrad_s2(ph, pw):
+                assert dh in (0, 1) and dw in (0, 1)
+                kh, kw = divmod(t, 3)
+                assert (ph + 1 - kh) % 2 == 0 and (pw + 1 - kw) % 2 == 0
+                seen.append(t)
+    assert sorted(seen) == list(range(9))
+
+
+def test_cout_padding_rule():
+    from multigriddet_amd.ops import pad_cout
+    for co in (32, 64, 88, 128, 176, 256, 352, 512, 704, 1024):
+        p = pad_cout(co)
+        assert p >= co and p % 32 == 0 and p / co <= 1.125 + 1e-9 or p == -(-co // 32) * 32
+
+
+def test_bucket_tiling():
+    from multigriddet_amd.dp import make_buckets
+    from multigriddet_amd.engine import conv_specs
+    offs, off = [], 0
+    for sp in conv_specs():
+        offs.append(off)
+        off += sp["cout"] * sp["k"] ** 2 * sp["cin"] + sp["cout"] * (2 if sp["bn"] else 1)
+    assert off == 44954760
+    bk = make_buckets(offs, off, int(32e6 / 4))
+    assert bk[0][2] == off and bk[-1][1] == 0 and bk[-1][0] == 0
+    for (i0, b0, e0), (i1, b1, e1) in zip(bk, bk[1:]):
+        assert e1 == b0 and i1 < i0
+    assert sum(e - b for _, b, e in bk) == off

@@ -68,9 +68,11 @@ def test_forward_backward_vs_oracle(setup):
             tb[b, t] = [cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, rng.integers(0, 80)]
     yt = ot.tf_preprocess_true_boxes(tb, (S, S), coco_anchors(), 80)
 
-    # ---- oracle: fp32 torch CPU, training-mode BN
+    # ---- oracle: torch CPU, training-mode BN, bf16 storage emulated at the product's rounding points
+    # (pure-fp32 oracle differs by 6-17 % rel-L2 at this tiny size purely from bf16 noise amplified by
+    # BatchNorm over 64-sample statistics; see tests/debug_layers.py)
     tp = om.torch_params(params, requires_grad=True)
-    outs_ref = om.forward(torch.from_numpy(img), tp, training=True)
+    outs_ref = om.forward(torch.from_numpy(img), tp, training=True, emulate_bf16=True)
     lo = MultiGridLossOracle(coco_anchors(), 80, (S, S))
     loss_ref = lo([torch.from_numpy(y) for y in yt], outs_ref)
     loss_ref.backward()
@@ -82,7 +84,7 @@ def test_forward_backward_vs_oracle(setup):
     torch.cuda.synchronize()
     for l in range(3):
         r = rel_l2(outs[l].cpu().numpy(), outs_ref[l].detach().numpy())
-        assert r < 0.05, f"head {l} rel-L2 {r}"
+        assert r < 0.02, f"head {l} rel-L2 {r}"
     grids = [(S // 32,) * 2, (S // 16,) * 2, (S // 8,) * 2]
     cfg = ops.make_loss_cfg(coco_anchors(), 80, (S, S), B, grids)
     run = ops.LossRunner(cfg, net.device)
@@ -114,12 +116,12 @@ def test_inference_mode_and_frozen_backbone(setup):
     B, S = 2, 96
     img = np.random.default_rng(1).random((B, S, S, 3), dtype=np.float32)
     tp = om.torch_params(params)
-    ref = om.forward(torch.from_numpy(img), tp, training=False)
+    ref = om.forward(torch.from_numpy(img), tp, training=False, emulate_bf16=True)
     net.training = False
     outs = net.forward(torch.from_numpy(img).cuda())
     torch.cuda.synchronize()
     for l in range(3):
-        assert rel_l2(outs[l].cpu().numpy(), ref[l].numpy()) < 0.05
+        assert rel_l2(outs[l].cpu().numpy(), ref[l].numpy()) < 0.02
     net.training = True
 
 
