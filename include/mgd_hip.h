@@ -137,6 +137,10 @@ int mgd_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
  * weight_decay > 0 gives AdamW (decoupled, Keras: p -= lr*wd*p). */
 int mgd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int step, float grad_scale, float weight_decay, void* stream);
+/* Same update with lr_t = hyper[0] and lr*weight_decay = hyper[1] read from DEVICE memory, so that a
+ * captured hipGraph of the whole step can be replayed while the schedule / bias correction advance. */
+int mgd_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,
+                      float beta2, float eps, float grad_scale, void* stream);
 int mgd_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, float momentum, int nesterov,
                  float grad_scale, void* stream);
 

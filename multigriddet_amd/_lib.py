@@ -80,7 +80,7 @@ EXPORTS = [
     "mgd_last_error", "mgd_version", "mgd_conv_gather_gemm", "mgd_conv_wgrad", "mgd_stem_fwd", "mgd_stem_wgrad",
     "mgd_pack_weights", "mgd_bn_finalize", "mgd_bn_act_fwd", "mgd_bn_act_bwd_reduce", "mgd_bn_act_bwd_apply",
     "mgd_upsample_concat_fwd", "mgd_upsample_concat_bwd", "mgd_bias_grad", "mgd_f32_to_bf16", "mgd_bf16_to_f32",
-    "mgd_adam_step", "mgd_sgd_step", "mgd_build_targets_workspace_size", "mgd_build_targets",
+    "mgd_adam_step", "mgd_adam_step_dev", "mgd_sgd_step", "mgd_build_targets_workspace_size", "mgd_build_targets",
     "mgd_loss_workspace_size", "mgd_loss_fwd_bwd", "mgd_decode_workspace_size", "mgd_decode",
     "mgd_nms_workspace_size", "mgd_nms", "mgd_mosaic", "mgd_gridmask", "mgd_mixup",
 ]

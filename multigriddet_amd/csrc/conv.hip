@@ -13,6 +13,7 @@
 // channels of one pixel per accumulator tile - 8-byte packed bf16 pieces that are staged through LDS
 // and leave as whole 16-byte/256-byte NHWC rows.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -234,6 +235,230 @@ __global__ __launch_bounds__(256) void conv_gather_gemm_kernel(GemmArgs a) {
     }
   }
   const int CPR = BNC * esz / 16;  // 16-byte chunks per row
+  for (int q = tid; q < BMP * CPR; q += 256) {
+    int r = q / CPR, ch = q - r * CPR;
+    long long off = row_dst[r];
+    int c = co0 + ch * (16 / esz);
+    if (off < 0 || c >= a.Co) continue;
+    uint4 v = *(const uint4*)(smem + r * EROW + ch * 16);
+    if (a.dst_f32) {
+      *(uint4*)((float*)a.dst + off + c) = v;
+    } else {
+      if (a.addend) {
+        uint4 ad = *(const uint4*)(a.addend + off + c);
+        float f[8], g[8];
+        unpack8(v, f);
+        unpack8(ad, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += g[j];
+        v = pack8(f);
+      }
+      *(uint4*)((bf16_t*)a.dst + off + c) = v;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// v2: LDS-DMA (global_load_lds) staging into an NST-deep LDS ring with counted vmcnt and one raw
+// s_barrier per K-step - the loads of NST-1 stages stay in flight across barriers, which is what hides
+// the L2/HBM latency the register-staged kernel above exposes (it measured ~2 us per K-step).
+// LDS image per stage: W tile [BNC][64 bf16] then X tile [128][64 bf16], rows of 128 B, the 16-byte
+// chunk kc of row r stored at slot kc ^ (r & 7).  LDS-DMA writes lane-linear (base + lane*16), so the
+// swizzle is applied on the per-lane SOURCE address; zero padding comes from a zero page in HBM.
+// All LDS lives in one dynamic array (a second __shared__ object makes hipcc drain vmcnt early).
+__device__ uint4 g_zero_page[8];
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WC, int WP, int MT, int NT, int NST>
+__global__ __launch_bounds__(256) void conv_gemm2_kernel(GemmArgs a) {
+  constexpr int BNC = WC * MT * 16;
+  constexpr int BMP = WP * NT * 16;
+  static_assert(WC * WP == 4 && BMP == 128, "tile");
+  constexpr int WCH = BNC / 32;   // weight glds per thread per stage
+  constexpr int XCH = 4;          // pixel glds per thread per stage
+  constexpr int LPS = WCH + XCH;  // loads per stage per wave
+  constexpr int STAGE = (BNC + BMP) * ROWB;
+  constexpr int AUX = NST * STAGE;                 // row_dst (128 x 8 B) + colred (256 x 4 B)
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  long long* row_dst = (long long*)(smem + AUX);
+  float* colred = (float*)(smem + AUX + 1024);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wc = wave / WP, wp = wave % WP;
+
+  const int L = xcd_remap(blockIdx.x, a.nblk);
+  const int tc = L % a.tilesC, tp = L / a.tilesC;
+  const int co0 = tc * BNC;
+  const int pix0 = tp * BMP;
+
+  if (tid < BMP) {
+    int m = pix0 + tid;
+    long long off = -1;
+    if (m < a.M) {
+      int hw = a.Hg * a.Wg;
+      int n = m / hw, rem = m - n * hw;
+      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+      int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
+      off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
+    }
+    row_dst[tid] = off;
+  }
+
+  // thread -> LDS slot (tid & 7) of rows (tid >> 3) + 32 i ; source chunk kc = slot ^ (row & 7)
+  const int rlo = tid >> 3;
+  const int kc = (tid & 7) ^ (rlo & 7);
+  const bf16_t* xrow[XCH];
+  int hs0[XCH], ws0[XCH];
+#pragma unroll
+  for (int i = 0; i < XCH; ++i) {
+    int m = pix0 + rlo + 32 * i;
+    if (m < a.M) {
+      int hw = a.Hg * a.Wg;
+      int n = m / hw, rem = m - n * hw;
+      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+      hs0[i] = ig * a.in_stride;
+      ws0[i] = jg * a.in_stride;
+      xrow[i] = a.src + (((long long)n * a.Hs + hs0[i]) * a.Ws + ws0[i]) * a.Ci;
+    } else {
+      hs0[i] = -(1 << 20);
+      ws0[i] = -(1 << 20);
+      xrow[i] = a.src;
+    }
+  }
+  int tap = (kc * 8) / a.Ci;
+  int cch = (kc * 8) - tap * a.Ci;
+  const bf16_t* wrow[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) wrow[i] = a.wpk + (long long)(co0 + rlo + 32 * i) * a.K_pad + kc * 8;
+  const void* zero = (const void*)g_zero_page;
+
+  auto issue = [&](int ks, int buf) {
+    unsigned char* wb = smem + buf * STAGE + wave * 1024;          // wave covers rows 8*wave .. +7 of each 32-row group
+    unsigned char* xb = smem + buf * STAGE + BNC * ROWB + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) glds16(wrow[i] + ks * BK, wb + i * 4096);
+    int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
+    int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
+    bool tv = tap < a.ntaps;
+    long long toff = ((long long)dh * a.Ws + dw) * a.Ci + cch;
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      bool v = tv && (unsigned)(hs0[i] + dh) < (unsigned)a.Hs && (unsigned)(ws0[i] + dw) < (unsigned)a.Ws;
+      const void* g = v ? (const void*)(xrow[i] + toff) : zero;
+      glds16(g, xb + i * 4096);
+    }
+    cch += BK;
+    while (cch >= a.Ci) {
+      cch -= a.Ci;
+      ++tap;
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K_pad / BK;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue(s, s);
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int ks = 0; ks < nk; ++ks) {
+    // stages issued beyond ks so far
+    int pending = min(NST - 2, nk - 1 - ks);
+    if (NST >= 4 && pending >= 2) wait_vmcnt<2 * LPS>();
+    else if (NST >= 3 && pending == 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (ks + NST - 1 < nk) issue(ks + NST - 1, (ks + NST - 1) % NST);
+    const unsigned char* wb = smem + (ks % NST) * STAGE;
+    const unsigned char* xb = wb + BNC * ROWB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 wf[MT], xf[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(wb + lds_off((wc * MT + m) * 16 + fr, kk * 4 + fq));
+#pragma unroll
+      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(xb + lds_off((wp * NT + n) * 16 + fr, kk * 4 + fq));
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue (same as v1)
+  const int esz = a.dst_f32 ? 4 : 2;
+  const int EROW = BNC * esz + 16;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    int cl = (wc * MT + m) * 16 + fq * 4;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (a.bias) {
+      int c = co0 + cl;
+      if (c + 3 < a.Co) { b0 = a.bias[c]; b1 = a.bias[c + 1]; b2 = a.bias[c + 2]; b3 = a.bias[c + 3]; }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      int pl = (wp * NT + n) * 16 + fr;
+      f32x4 v = acc[m][n];
+      v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+      if (a.dst_f32) {
+        *(f32x4*)(smem + pl * EROW + cl * 4) = v;
+      } else {
+        uint2 p;
+        p.x = pack2bf(v[0], v[1]);
+        p.y = pack2bf(v[2], v[3]);
+        *(uint2*)(smem + pl * EROW + cl * 2) = p;
+      }
+    }
+  }
+  __syncthreads();
+  const int rows_valid = min(BMP, a.M - pix0);
+  if (a.stats && !a.dst_f32) {
+    constexpr int NCP = BNC / 2, RG = 256 / NCP, RPG = BMP / RG;
+    if (tid < 2 * BNC) colred[tid] = 0.f;
+    __syncthreads();
+    int cp = tid % NCP, rg = tid / NCP;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    int rend = min(rows_valid, (rg + 1) * RPG);
+    for (int r = rg * RPG; r < rend; ++r) {
+      uint32_t u = *(const uint32_t*)(smem + r * EROW + cp * 4);
+      float v0 = __uint_as_float(u << 16), v1 = __uint_as_float(u & 0xffff0000u);
+      s0 += v0; s1 += v1; q0 += v0 * v0; q1 += v1 * v1;
+    }
+    atomicAdd(&colred[2 * cp], s0);
+    atomicAdd(&colred[2 * cp + 1], s1);
+    atomicAdd(&colred[BNC + 2 * cp], q0);
+    atomicAdd(&colred[BNC + 2 * cp + 1], q1);
+    __syncthreads();
+    if (tid < 2 * BNC) {
+      int which = tid / BNC, col = tid - which * BNC;
+      if (co0 + col < a.Co) {
+        int rep = blockIdx.x % a.stats_replicas;
+        atomicAdd(a.stats + ((long long)rep * 2 + which) * a.Co + co0 + col, colred[tid]);
+      }
+    }
+  }
+  const int CPR = BNC * esz / 16;
   for (int q = tid; q < BMP * CPR; q += 256) {
     int r = q / CPR, ch = q - r * CPR;
     long long off = row_dst[r];
@@ -590,6 +815,26 @@ int launch_gemm(GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
+
+template <int WC, int WP, int MT, int NT, int NST>
+int launch_gemm2(GemmArgs& a, hipStream_t st) {
+  constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
+  a.tilesC = a.Co_pad / BNC;
+  int tilesP = cdiv(a.M, BMP);
+  a.nblk = a.tilesC * tilesP;
+  size_t ring = (size_t)NST * (BNC + BMP) * ROWB + 2048;
+  size_t epi = (size_t)BMP * (BNC * (a.dst_f32 ? 4 : 2) + 16);
+  if (epi > (size_t)NST * (BNC + BMP) * ROWB) ring = epi + 2048 > ring ? epi + 2048 : ring;
+  auto k = conv_gemm2_kernel<WC, WP, MT, NT, NST>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), ring, st, a);
+  return 0;
+}
+
 template <int WC, int WI, int MT, int NT>
 int launch_wgrad(WgradArgs& a, hipStream_t st) {
   constexpr int BCO = WC * MT * 16, BCI = WI * NT * 16;
@@ -635,9 +880,26 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   a.K_pad = d->K_pad; a.Co_pad = d->Co_pad; a.dst_f32 = d->dst_f32; a.stats_replicas = d->stats_replicas;
   a.M = d->N * d->Hg * d->Wg;
   hipStream_t st = (hipStream_t)stream;
-  if (d->Co_pad % 128 == 0) launch_gemm<2, 2, 4, 4>(a, st);
-  else if (d->Co_pad % 64 == 0) launch_gemm<1, 4, 4, 2>(a, st);
-  else launch_gemm<1, 4, 2, 2>(a, st);
+  static int variant = -1;
+  if (variant < 0) {
+    const char* e = getenv("MGD_GEMM");
+    variant = e ? atoi(e) : 3;
+  }
+  const int nk = d->K_pad / BK;
+  if (variant == 1) {
+    if (d->Co_pad % 128 == 0) launch_gemm<2, 2, 4, 4>(a, st);
+    else if (d->Co_pad % 64 == 0) launch_gemm<1, 4, 4, 2>(a, st);
+    else launch_gemm<1, 4, 2, 2>(a, st);
+  } else {
+    const bool deep = (variant == 2) ? nk >= 6 : (variant == 4);
+    if (d->Co_pad % 128 == 0) {
+      if (deep) launch_gemm2<2, 2, 4, 4, 4>(a, st); else launch_gemm2<2, 2, 4, 4, 2>(a, st);
+    } else if (d->Co_pad % 64 == 0) {
+      if (deep) launch_gemm2<1, 4, 4, 2, 4>(a, st); else launch_gemm2<1, 4, 4, 2, 2>(a, st);
+    } else {
+      if (deep) launch_gemm2<1, 4, 2, 2, 4>(a, st); else launch_gemm2<1, 4, 2, 2, 2>(a, st);
+    }
+  }
   MGD_CHECK_LAUNCH("conv_gather_gemm");
   return MGD_OK;
 }

@@ -254,7 +254,9 @@ __global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restr
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n, float lr_t,
-                                                   float b1, float b2, float eps, float gscale, float lr_wd) {
+                                                   float b1, float b2, float eps, float gscale, float lr_wd,
+                                                   const float* __restrict__ hyper) {
+  if (hyper) { lr_t = hyper[0]; lr_wd = hyper[1]; }
   long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   for (; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
     if (i + 3 < n) {
@@ -421,8 +423,17 @@ extern "C" int mgd_adam_step(float* p, const float* g, float* m, float* v, int64
   MGD_REQUIRE(p && g && m && v && step >= 1, "adam: bad arguments");
   double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
-                     (float)lr_t, beta1, beta2, eps, grad_scale, lr * weight_decay);
+                     (float)lr_t, beta1, beta2, eps, grad_scale, lr * weight_decay, (const float*)nullptr);
   MGD_CHECK_LAUNCH("adam");
+  return MGD_OK;
+}
+
+extern "C" int mgd_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                                 float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  MGD_REQUIRE(p && g && m && v && hyper, "adam_dev: null pointer");
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
+                     0.f, beta1, beta2, eps, grad_scale, 0.f, hyper);
+  MGD_CHECK_LAUNCH("adam_dev");
   return MGD_OK;
 }
 

@@ -247,6 +247,13 @@ def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0, 
                                    C.c_float(weight_decay), L.stream_ptr()), "adam")
 
 
+def adam_step_dev(p, g, m, v, hyper, b1=0.9, b2=0.999, eps=1e-7, grad_scale=1.0):
+    """hyper: device fp32 [2] = (lr_t, lr*weight_decay); see mgd_adam_step_dev."""
+    L.check(L.load().mgd_adam_step_dev(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), C.c_int64(p.numel()), L.ptr(hyper),
+                                       C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(grad_scale),
+                                       L.stream_ptr()), "adam_dev")
+
+
 def sgd_step(p, g, mom, lr, momentum=0.937, nesterov=True, grad_scale=1.0):
     L.check(L.load().mgd_sgd_step(L.ptr(p), L.ptr(g), L.ptr(mom), C.c_int64(p.numel()), C.c_float(lr),
                                   C.c_float(momentum), int(nesterov), C.c_float(grad_scale), L.stream_ptr()), "sgd")
