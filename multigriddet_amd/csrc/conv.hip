@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(GemmArgs a) {
   constexpr int XCH = 4;          // pixel glds per thread per stage
   constexpr int LPS = WCH + XCH;  // loads per stage per wave
   constexpr int STAGE = (BNC + BMP) * ROWB;
-  constexpr int AUX = NST * STAGE;                 // row_dst (128 x 8 B) + colred (256 x 4 B)
+  constexpr int EPI_MAX = BMP * (BNC * 4 + 16);    // fp32 epilogue tile (largest user of the region)
+  constexpr int AUX = NST * STAGE > EPI_MAX ? NST * STAGE : EPI_MAX;   // then row_dst (128 x 8 B) + colred (256 x 4 B)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   long long* row_dst = (long long*)(smem + AUX);
@@ -664,6 +665,145 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient v2: same MFMA/tr-read structure, operands staged by LDS-DMA into a 2-deep ring
+// (one raw barrier per 64-pixel K-step, the next stage's loads in flight during the MFMAs).
+template <int WC, int WI, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
+  constexpr int BCO = WC * MT * 16;
+  constexpr int BCI = WI * NT * 16;
+  static_assert(WC * WI == 4, "4 waves");
+  constexpr int RBO = BCO * 2, RBI = BCI * 2;
+  constexpr int OCH = RBO / 64, ICH = RBI / 64;        // LDS-DMA instructions per wave per stage
+  constexpr int ORPI = 1024 / RBO, IRPI = 1024 / RBI;  // rows per wave-instruction
+  constexpr int STAGE = 64 * (RBO + RBI);
+  constexpr int EROW = (BCI + 4) * 4;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave / WI, wi = wave % WI;
+
+  int b = blockIdx.x;
+  const int tco = b % a.tilesCo; b /= a.tilesCo;
+  const int tci = b % a.tilesCi; b /= a.tilesCi;
+  const int tap = b % a.ntaps;
+  const int split = b / a.ntaps;
+  const int co0 = tco * BCO, ci0 = tci * BCI;
+  const int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
+  const int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
+  const int pbeg = split * a.chunk;
+  const int pend = min(a.P, pbeg + a.chunk);
+  const int nk = (pend - pbeg + 63) / 64;
+  const void* zero = (const void*)g_zero_page;
+
+  // per-thread (row-in-group, logical chunk) for both tiles
+  const int o_rl = lane / (RBO / 16), o_s = lane % (RBO / 16);
+  const int i_rl = lane / (RBI / 16), i_s = lane % (RBI / 16);
+
+  auto issue = [&](int ks, int buf) {
+    const int p0 = pbeg + ks * 64;
+    unsigned char* ob = smem + buf * STAGE;
+    unsigned char* ib = ob + 64 * RBO;
+#pragma unroll
+    for (int i = 0; i < OCH; ++i) {
+      int r = (i * 4 + wave) * ORPI + o_rl;
+      int ch = (((o_s >> 1) ^ tr_swz(r, RBO / 32)) << 1) | (o_s & 1);
+      int p = p0 + r, c = co0 + ch * 8;
+      const void* g = (p < pend && c < a.Co) ? (const void*)(a.dy + (long long)p * a.Co + c) : zero;
+      glds16(g, ob + (i * 4 + wave) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < ICH; ++i) {
+      int r = (i * 4 + wave) * IRPI + i_rl;
+      int ch = (((i_s >> 1) ^ tr_swz(r, RBI / 32)) << 1) | (i_s & 1);
+      int p = p0 + r, c = ci0 + ch * 8;
+      const void* g = zero;
+      if (p < pend && c < a.Ci) {
+        const int hw = a.Hg * a.Wg;
+        int n = (int)((float)p * a.rcp_hw);
+        int rem = p - n * hw;
+        while (rem < 0) { --n; rem += hw; }
+        while (rem >= hw) { ++n; rem -= hw; }
+        int ig = (int)((float)rem * a.rcp_w);
+        int jg = rem - ig * a.Wg;
+        while (jg < 0) { --ig; jg += a.Wg; }
+        while (jg >= a.Wg) { ++ig; jg -= a.Wg; }
+        int hs = ig * a.in_stride + dh, ws = jg * a.in_stride + dw;
+        if ((unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws)
+          g = (const void*)(a.src + (((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci + c);
+      }
+      glds16(g, ib + (i * 4 + wave) * 1024);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) issue(0, 0);
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  for (int ks = 0; ks < nk; ++ks) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
+    const unsigned char* ob = smem + (ks & 1) * STAGE;
+    const unsigned char* ib = ob + 64 * RBO;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int r0 = kk * 32 + 8 * g + qq;
+      bf16x8 of[MT], xf[NT];
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        int c32 = wc * MT + m;
+        s16x4 lo = ds_read_tr16(ob + r0 * RBO + ((c32 ^ tr_swz(r0, RBO / 32)) * 32) + pp * 8);
+        s16x4 hi = ds_read_tr16(ob + (r0 + 4) * RBO + ((c32 ^ tr_swz(r0 + 4, RBO / 32)) * 32) + pp * 8);
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        of[m] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        int c32 = wi * NT + n;
+        s16x4 lo = ds_read_tr16(ib + r0 * RBI + ((c32 ^ tr_swz(r0, RBI / 32)) * 32) + pp * 8);
+        s16x4 hi = ds_read_tr16(ib + (r0 + 4) * RBI + ((c32 ^ tr_swz(r0 + 4, RBI / 32)) * 32) + pp * 8);
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        xf[n] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of[m], xf[n], acc[m][n], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int col = (wc * MT + m) * 16 + fq * 4 + r;
+        int cil = (wi * NT + n) * 16 + fr;
+        *(float*)(smem + col * EROW + cil * 4) = acc[m][n][r];
+      }
+  __syncthreads();
+  for (int q = tid; q < BCO * BCI; q += 256) {
+    int col = q / BCI, cil = q - col * BCI;
+    int co = co0 + col, ci = ci0 + cil;
+    if (co < a.Co && ci < a.Ci) {
+      float v = *(const float*)(smem + col * EROW + cil * 4);
+      atomicAdd(a.dw + ((long long)co * a.ntaps + tap) * a.Ci + ci, v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Stem: 3x3, 3 -> 32, fp32 image in, bf16 out.  HBM-bound (writes 64 B per pixel); direct VALU.
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
@@ -808,7 +948,7 @@ int launch_gemm(GemmArgs& a, hipStream_t st) {
   auto k = conv_gather_gemm_kernel<WC, WP, MT, NT>;
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
     attr = true;
   }
   hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), lds, st, a);
@@ -822,9 +962,9 @@ int launch_gemm2(GemmArgs& a, hipStream_t st) {
   a.tilesC = a.Co_pad / BNC;
   int tilesP = cdiv(a.M, BMP);
   a.nblk = a.tilesC * tilesP;
-  size_t ring = (size_t)NST * (BNC + BMP) * ROWB + 2048;
-  size_t epi = (size_t)BMP * (BNC * (a.dst_f32 ? 4 : 2) + 16);
-  if (epi > (size_t)NST * (BNC + BMP) * ROWB) ring = epi + 2048 > ring ? epi + 2048 : ring;
+  size_t ring = (size_t)NST * (BNC + BMP) * ROWB;
+  size_t epi = (size_t)BMP * (BNC * 4 + 16);       // must match AUX in the kernel
+  ring = (ring > epi ? ring : epi) + 2048;
   auto k = conv_gemm2_kernel<WC, WP, MT, NT, NST>;
   static bool attr = false;
   if (!attr) {
@@ -843,10 +983,16 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   size_t stage = (size_t)64 * (BCO + BCI) * 2 * 2;
   size_t epi = (size_t)BCO * (BCI + 4) * 4;
   size_t lds = stage > epi ? stage : epi;
-  auto k = conv_wgrad_kernel<WC, WI, MT, NT>;
+  static int variant = -1;
+  if (variant < 0) {
+    const char* e = getenv("MGD_WGRAD");
+    variant = e ? atoi(e) : 2;
+  }
+  auto k = variant == 1 ? conv_wgrad_kernel<WC, WI, MT, NT> : conv_wgrad2_kernel<WC, WI, MT, NT>;
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<WC, WI, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<WC, WI, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
     attr = true;
   }
   int nblk = a.tilesCo * a.tilesCi * a.ntaps * a.splits;

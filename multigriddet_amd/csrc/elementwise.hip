@@ -99,25 +99,41 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
   if (active) {
-    for (long long p = (long long)blockIdx.x * PL + pl; p < P; p += (long long)gridDim.x * PL) {
-      long long e = p * C + oct * 8;
-      float g[8], v[8];
-      unpack8(*(const uint4*)(da + e), g);
-      unpack8(*(const uint4*)(y + e), v);
-      float o[8];
+    constexpr int U = 4;                      // pixels in flight per thread: 8 x 16-byte loads before any use
+    const long long stride = (long long)gridDim.x * PL;
+    for (long long p0 = (long long)blockIdx.x * PL + pl; p0 < P; p0 += stride * U) {
+      uint4 gv[U], yv[U];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float z = fmaf(v[j], sc[j], sh[j]);
-        float d = z > 0.f ? g[j] : g[j] * slope;
-        float yh = (v[j] - mu[j]) * iv[j];
-        if (APPLY) {
-          o[j] = frozen ? sc[j] * d : sc[j] * (d - m1[j] - yh * m2[j]);
-        } else {
-          s1[j] += d;
-          s2[j] += d * yh;
+      for (int u = 0; u < U; ++u) {
+        long long p = p0 + u * stride;
+        if (p < P) {
+          long long e = p * C + oct * 8;
+          gv[u] = *(const uint4*)(da + e);
+          yv[u] = *(const uint4*)(y + e);
         }
       }
-      if (APPLY) *(uint4*)(dy + e) = pack8(o);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        long long p = p0 + u * stride;
+        if (p >= P) break;
+        long long e = p * C + oct * 8;
+        float g[8], v[8], o[8];
+        unpack8(gv[u], g);
+        unpack8(yv[u], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float z = fmaf(v[j], sc[j], sh[j]);
+          float d = z > 0.f ? g[j] : g[j] * slope;
+          float yh = (v[j] - mu[j]) * iv[j];
+          if (APPLY) {
+            o[j] = frozen ? sc[j] * d : sc[j] * (d - m1[j] - yh * m2[j]);
+          } else {
+            s1[j] += d;
+            s2[j] += d * yh;
+          }
+        }
+        if (APPLY) *(uint4*)(dy + e) = pack8(o);
+      }
     }
   }
   if (!APPLY) {
