@@ -35,6 +35,7 @@ struct GemmArgs {
   int M;        // N*Hg*Wg
   int tilesC;   // Co_pad / BNC
   int nblk;
+  int dbg;      // diagnostic only (MGD_DBG): 1 = all LDS-DMA loads hit one cache line
 };
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * ROWB + ((kc ^ (row & 7)) << 4); }
@@ -280,20 +281,22 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int WC, int WP, int MT, int NT, int NST>
-__global__ __launch_bounds__(256) void conv_gemm2_kernel(GemmArgs a) {
+__global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
   constexpr int BNC = WC * MT * 16;
   constexpr int BMP = WP * NT * 16;
-  static_assert(WC * WP == 4 && BMP == 128, "tile");
-  constexpr int WCH = BNC / 32;   // weight glds per thread per stage
-  constexpr int XCH = 4;          // pixel glds per thread per stage
+  constexpr int NTHR = 64 * WC * WP;      // 4 waves (128-pixel tile, 2 blocks/CU) or 8 waves (256-pixel tile)
+  constexpr int RPR = NTHR / 8;            // tile rows covered by one LDS-DMA round of the block
+  static_assert(BMP % RPR == 0 && BNC % RPR == 0, "tile/threads");
+  constexpr int WCH = BNC / RPR;  // weight glds per thread per stage
+  constexpr int XCH = BMP / RPR;  // pixel glds per thread per stage
   constexpr int LPS = WCH + XCH;  // loads per stage per wave
   constexpr int STAGE = (BNC + BMP) * ROWB;
   constexpr int EPI_MAX = BMP * (BNC * 4 + 16);    // fp32 epilogue tile (largest user of the region)
-  constexpr int AUX = NST * STAGE > EPI_MAX ? NST * STAGE : EPI_MAX;   // then row_dst (128 x 8 B) + colred (256 x 4 B)
+  constexpr int AUX = NST * STAGE > EPI_MAX ? NST * STAGE : EPI_MAX;   // then row_dst (BMP x 8 B) + colred (256 x 4 B)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   long long* row_dst = (long long*)(smem + AUX);
-  float* colred = (float*)(smem + AUX + 1024);
+  float* colred = (float*)(smem + AUX + BMP * 8);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -318,48 +321,60 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(GemmArgs a) {
     row_dst[tid] = off;
   }
 
-  // thread -> LDS slot (tid & 7) of rows (tid >> 3) + 32 i ; source chunk kc = slot ^ (row & 7)
+  // thread -> LDS slot (tid & 7) of rows (tid >> 3) + RPR i ; source chunk kc = slot ^ (row & 7).
+  // Address generation is kept off the critical path (the first version spent 5.7 VALU instructions
+  // per MFMA on it): per row a 32-bit byte offset and a 9-bit tap-validity mask are computed once; per
+  // K-step a load costs a mask test, a select and an add, with the tensor base in SGPRs.  Out-of-image
+  // taps load from offset 0 (any valid address) and the owning lane overwrites its 16-byte LDS slot
+  // with zeros once its own DMA has landed (before the barrier that publishes the stage).
   const int rlo = tid >> 3;
   const int kc = (tid & 7) ^ (rlo & 7);
-  const bf16_t* xrow[XCH];
-  int hs0[XCH], ws0[XCH];
+  unsigned xoff[XCH];
+  unsigned vmask[XCH];
 #pragma unroll
   for (int i = 0; i < XCH; ++i) {
-    int m = pix0 + rlo + 32 * i;
+    int m = pix0 + rlo + RPR * i;
+    xoff[i] = 0;
+    vmask[i] = 0;
     if (m < a.M) {
       int hw = a.Hg * a.Wg;
       int n = m / hw, rem = m - n * hw;
       int ig = rem / a.Wg, jg = rem - ig * a.Wg;
-      hs0[i] = ig * a.in_stride;
-      ws0[i] = jg * a.in_stride;
-      xrow[i] = a.src + (((long long)n * a.Hs + hs0[i]) * a.Ws + ws0[i]) * a.Ci;
-    } else {
-      hs0[i] = -(1 << 20);
-      ws0[i] = -(1 << 20);
-      xrow[i] = a.src;
+      int hs = ig * a.in_stride, ws = jg * a.in_stride;
+      xoff[i] = (unsigned)(((((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci) * 2);
+      for (int t = 0; t < a.ntaps; ++t) {
+        int dh = (int)((a.tapcode >> (4 * t)) & 3) - 1, dw = (int)((a.tapcode >> (4 * t + 2)) & 3) - 1;
+        if ((unsigned)(hs + dh) < (unsigned)a.Hs && (unsigned)(ws + dw) < (unsigned)a.Ws) vmask[i] |= 1u << t;
+      }
     }
   }
   int tap = (kc * 8) / a.Ci;
   int cch = (kc * 8) - tap * a.Ci;
-  const bf16_t* wrow[WCH];
+  unsigned woff[WCH];
 #pragma unroll
-  for (int i = 0; i < WCH; ++i) wrow[i] = a.wpk + (long long)(co0 + rlo + 32 * i) * a.K_pad + kc * 8;
-  const void* zero = (const void*)g_zero_page;
+  for (int i = 0; i < WCH; ++i) woff[i] = (unsigned)(((long long)(co0 + rlo + RPR * i) * a.K_pad + kc * 8) * 2);
+  const char* xbase = (const char*)a.src;
+  const char* wbase = (const char*)a.wpk;
+  // my LDS slots (byte offsets inside a stage) for the zero fix-up
 
+  unsigned inv_next = 0;
   auto issue = [&](int ks, int buf) {
-    unsigned char* wb = smem + buf * STAGE + wave * 1024;          // wave covers rows 8*wave .. +7 of each 32-row group
+    unsigned char* wb = smem + buf * STAGE + wave * 1024;
     unsigned char* xb = smem + buf * STAGE + BNC * ROWB + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < WCH; ++i) glds16(wrow[i] + ks * BK, wb + i * 4096);
+    for (int i = 0; i < WCH; ++i)
+      glds16(wbase + ((a.dbg & 1) ? 0u : woff[i] + (unsigned)ks * (BK * 2)), wb + i * (RPR * ROWB));
     int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
     int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
-    bool tv = tap < a.ntaps;
-    long long toff = ((long long)dh * a.Ws + dw) * a.Ci + cch;
+    int toff = ((dh * a.Ws + dw) * a.Ci + cch) * 2;
+    inv_next = 0;
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
-      bool v = tv && (unsigned)(hs0[i] + dh) < (unsigned)a.Hs && (unsigned)(ws0[i] + dw) < (unsigned)a.Ws;
-      const void* g = v ? (const void*)(xrow[i] + toff) : zero;
-      glds16(g, xb + i * 4096);
+      bool v = (vmask[i] >> tap) & 1u;
+      unsigned off = v ? xoff[i] + (unsigned)toff : 0u;
+      if (a.dbg & 1) off = 0u;
+      if (!v) inv_next |= 1u << i;
+      glds16(xbase + off, xb + i * (RPR * ROWB));
     }
     cch += BK;
     while (cch >= a.Ci) {
@@ -375,28 +390,54 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(GemmArgs a) {
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = a.K_pad / BK;
+  // ring bookkeeping of the zero fix-up masks: stage s issued -> inv[s % NST]
+  unsigned inv[NST];
+#pragma unroll
+  for (int s = 0; s < NST; ++s) inv[s] = 0;
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) issue(s, s);
+    if (s < nk) { issue(s, s); inv[s] = inv_next; }
 
   const int fr = lane & 15, fq = lane >> 4;
+  // fragment read offsets inside a stage (k-half kk flips bit 6 of the byte offset)
+  int wro[MT], xro[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) wro[m] = lds_off((wc * MT + m) * 16 + fr, fq);
+#pragma unroll
+  for (int n = 0; n < NT; ++n) xro[n] = BNC * ROWB + lds_off((wp * NT + n) * 16 + fr, fq);
+  const int zslot = BNC * ROWB + (rlo * ROWB) + (tid & 7) * 16;   // + i * RPR*ROWB : my X slots
+
   for (int ks = 0; ks < nk; ++ks) {
-    // stages issued beyond ks so far
     int pending = min(NST - 2, nk - 1 - ks);
     if (NST >= 4 && pending >= 2) wait_vmcnt<2 * LPS>();
     else if (NST >= 3 && pending == 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
+    const int cur = ks % NST;
+    unsigned char* sb = smem + cur * STAGE;
+    unsigned invc = 0;
+#pragma unroll
+    for (int s = 0; s < NST; ++s)
+      if (s == cur) invc = inv[s];
+    if (invc) {
+#pragma unroll
+      for (int i = 0; i < XCH; ++i)
+        if (invc & (1u << i)) *(uint4*)(sb + zslot + i * (RPR * ROWB)) = make_uint4(0, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (ks + NST - 1 < nk) issue(ks + NST - 1, (ks + NST - 1) % NST);
-    const unsigned char* wb = smem + (ks % NST) * STAGE;
-    const unsigned char* xb = wb + BNC * ROWB;
+    if (ks + NST - 1 < nk) {
+      issue(ks + NST - 1, (ks + NST - 1) % NST);
+#pragma unroll
+      for (int s = 0; s < NST; ++s)
+        if (s == (ks + NST - 1) % NST) inv[s] = inv_next;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 wf[MT], xf[NT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(wb + lds_off((wc * MT + m) * 16 + fr, kk * 4 + fq));
+      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(sb + (wro[m] ^ (kk << 6)));
 #pragma unroll
-      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(xb + lds_off((wp * NT + n) * 16 + fr, kk * 4 + fq));
+      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + (xro[n] ^ (kk << 6)));
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -435,7 +476,7 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(GemmArgs a) {
   __syncthreads();
   const int rows_valid = min(BMP, a.M - pix0);
   if (a.stats && !a.dst_f32) {
-    constexpr int NCP = BNC / 2, RG = 256 / NCP, RPG = BMP / RG;
+    constexpr int NCP = BNC / 2, RG = NTHR / NCP, RPG = BMP / RG;
     if (tid < 2 * BNC) colred[tid] = 0.f;
     __syncthreads();
     int cp = tid % NCP, rg = tid / NCP;
@@ -460,7 +501,7 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(GemmArgs a) {
     }
   }
   const int CPR = BNC * esz / 16;
-  for (int q = tid; q < BMP * CPR; q += 256) {
+  for (int q = tid; q < BMP * CPR; q += NTHR) {
     int r = q / CPR, ch = q - r * CPR;
     long long off = row_dst[r];
     int c = co0 + ch * (16 / esz);
@@ -964,14 +1005,14 @@ int launch_gemm2(GemmArgs& a, hipStream_t st) {
   a.nblk = a.tilesC * tilesP;
   size_t ring = (size_t)NST * (BNC + BMP) * ROWB;
   size_t epi = (size_t)BMP * (BNC * 4 + 16);       // must match AUX in the kernel
-  ring = (ring > epi ? ring : epi) + 2048;
+  ring = (ring > epi ? ring : epi) + (size_t)BMP * 8 + 1024;
   auto k = conv_gemm2_kernel<WC, WP, MT, NT, NST>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), ring, st, a);
+  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(64 * WC * WP), ring, st, a);
   return 0;
 }
 
@@ -1025,6 +1066,9 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   MGD_REQUIRE(ok, "conv: tap offsets must lie in [-1,1]");
   a.K_pad = d->K_pad; a.Co_pad = d->Co_pad; a.dst_f32 = d->dst_f32; a.stats_replicas = d->stats_replicas;
   a.M = d->N * d->Hg * d->Wg;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("MGD_DBG"); dbg = e ? atoi(e) : 0; }
+  a.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;
   static int variant = -1;
   if (variant < 0) {
@@ -1036,6 +1080,9 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     if (d->Co_pad % 128 == 0) launch_gemm<2, 2, 4, 4>(a, st);
     else if (d->Co_pad % 64 == 0) launch_gemm<1, 4, 4, 2>(a, st);
     else launch_gemm<1, 4, 2, 2>(a, st);
+  } else if (variant == 5 && d->Co_pad % 64 == 0 && (long long)a.M * (d->Co_pad / (d->Co_pad % 128 == 0 ? 128 : 64)) >= 256ll * 200 && !d->dst_f32) {
+    // 8-wave, 256-pixel tile, 3-stage ring (1 block/CU): enough tiles to fill the chip
+    if (d->Co_pad % 128 == 0) launch_gemm2<2, 4, 4, 4, 3>(a, st); else launch_gemm2<1, 8, 4, 2, 3>(a, st);
   } else {
     const bool deep = (variant == 2) ? nk >= 6 : (variant == 4);
     if (d->Co_pad % 128 == 0) {

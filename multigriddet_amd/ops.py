@@ -150,11 +150,18 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None):
     return out
 
 
-def wgrad_splits(P, co, ci, T, target_blocks=768):
+import os as _os
+_WGRAD_BLOCKS = int(_os.environ.get("MGD_WGRAD_BLOCKS", "512"))
+
+
+def wgrad_splits(P, co, ci, T, target_blocks=None):
+    # measured (tools/bench_conv.py): the fp32-atomic epilogue costs as much as ~25 % of a block, so fewer,
+    # longer blocks win until the chip is under-filled: ~2 blocks/CU for 3x3, ~1 block/CU for 1x1.
+    target_blocks = target_blocks or (_WGRAD_BLOCKS if T > 1 else _WGRAD_BLOCKS // 2)
     bco = 128 if co > 64 else (64 if co > 32 else 32)
     bci = 128 if ci > 64 else (64 if ci > 32 else 32)
     base = -(-co // bco) * -(-ci // bci) * T
-    return max(1, min(target_blocks // base, -(-P // 256)))
+    return max(1, min(int(target_blocks / base + 0.5), -(-P // 256)))
 
 
 def conv_wgrad(x, dy, dw, k, s, splits=None):

@@ -49,6 +49,9 @@ CONV_CASES = [
     (1, 10, 10, 320, 64, 1, 1),
     (1, 38, 38, 64, 176, 3, 1),
     (2, 12, 12, 512, 1024, 3, 2),
+    (8, 96, 96, 64, 128, 3, 1),          # enough tiles for the 8-wave / 256-pixel-tile variant
+    (4, 128, 128, 32, 64, 3, 2),
+    (6, 100, 100, 128, 64, 1, 1),
 ]
 
 
