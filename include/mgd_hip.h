@@ -98,6 +98,22 @@ int mgd_stem_wgrad(const float* image, const void* dy, float* dw, int N, int H, 
 int mgd_pack_weights(const float* w, void* out, int Co, int T, int Ci, int transpose, int ntaps_out,
                      const int32_t* src_tap_host, int rows_pad, int K_pad, void* stream);
 
+/* All packed images of a network in ONE launch: `jobs_dev` is a device array of njobs descriptors sorted by
+ * `begin` (flat element index of the job's first output element); total = sum of rows_pad*K_pad. */
+typedef struct mgd_pack_job {
+  const float* w;      /* fp32 master weights [Co][T][Ci]          */
+  void* out;           /* bf16 image [rows_pad][K_pad]             */
+  int32_t Co, T, Ci, transpose, ntaps_out, rows_pad, K_pad, pad_;
+  uint64_t srccode;    /* 4 bits per output tap: source tap index  */
+  int64_t begin;
+} mgd_pack_job;
+int mgd_pack_weights_batch(const mgd_pack_job* jobs_dev, int njobs, int64_t total, void* stream);
+
+/* Stem as a GEMM: bf16 im2col [N*H*W][32] of the fp32 image (k = (kh*3+kw)*3+c, k >= 27 zero) so that the
+ * 3->32 conv (models/backbones/darknet.py:21) and its weight gradient run on the MFMA kernels as a 1x1
+ * conv with Ci = 32. */
+int mgd_stem_im2col(const float* image, void* out, int N, int H, int W, void* stream);
+
 /* ----------------------------------------------------------------------------------------------
  * BatchNorm (training mode, Keras defaults eps 1e-3 / momentum 0.99) + LeakyReLU(0.1) + residual
  * Replaces: BatchNormalization() + LeakyReLU(alpha=0.1) (layers.py:94-95), Add (darknet.py:39)

@@ -107,10 +107,19 @@ class Network:
             else:
                 cv.bias = self.params[cv.off_a:cv.off_a + C]
                 cv.dbias = self.grads[cv.off_a:cv.off_a + C]
-            cv.pk = None if cv.role == "stem" else ops.PackedConv(cv.cout, cv.cin, cv.k, cv.s, dev, need_dgrad=True)
+            if cv.role == "stem":       # 3x3x3 -> 32 runs as a 1x1 GEMM over the bf16 im2col image (K = 27 of 32)
+                cv.pk = ops.PackedConv(cv.cout, 32, 1, 1, dev, need_dgrad=False, ci_master=27)
+                cv.wpack = cv.w.view(cv.cout, 1, 27)
+            else:
+                cv.pk = ops.PackedConv(cv.cout, cv.cin, cv.k, cv.s, dev, need_dgrad=True)
+                cv.wpack = cv.w
+        self._pack_all = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers], dev)
+        self._pack_head = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers[BACKBONE_CONVS:]], dev)
+        self._stem_dw = torch.zeros(32, 1, 32, dtype=torch.float32, device=dev)
         self.training = True
         self.freeze_backbone = False
         self.freeze_all_but_pred = False
+        self.freeze_bn = False          # every BatchNorm on its moving statistics (convs stay trainable)
         self._arenas = {}
         self.reset_parameters(seed)
 
@@ -169,9 +178,8 @@ class Network:
         return out
 
     def refresh_packed(self, first=0):
-        for cv in self.layers[first:]:
-            if cv.pk is not None:
-                cv.pk.refresh(cv.w)
+        """Rewrite the bf16 GEMM images from the fp32 masters: one launch for the whole network."""
+        (self._pack_all if first == 0 else self._pack_head).run()
 
     def count_params(self):
         return self.n_params + self.moving.numel()
@@ -225,6 +233,7 @@ class Network:
                 A["cat"][sc] = torch.empty(B, 2 * gh, 2 * gw, lat.cout + skip_c, dtype=bf, device=dev)
                 i += 1
                 gh, gw = gh * 2, gw * 2
+        A["im2col"] = torch.empty(B, H, W, 32, dtype=bf, device=dev)
         A["scratch"] = {}
         self._arenas[key] = A
         return A
@@ -239,7 +248,7 @@ class Network:
 
     # ------------------------------------------------------------------ forward
     def _bn_training(self, cv):
-        if not self.training:
+        if not self.training or self.freeze_bn:
             return False
         if self.freeze_all_but_pred:
             return False
@@ -252,9 +261,8 @@ class Network:
         tr = self._bn_training(cv)
         y = A["y"][i]
         if cv.role == "stem":
-            ops.stem_fwd(x, cv.w, out=y, stats=cv.stats if tr else None)
-        else:
-            ops.conv_fwd(x, cv.pk, out=y, stats=cv.stats if tr else None)
+            x = ops.stem_im2col(x, out=A["im2col"])
+        ops.conv_fwd(x, cv.pk, out=y, stats=cv.stats if tr else None)
         P = y.numel() // cv.cout
         ops.bn_finalize(cv.stats, float(P), cv.gamma, cv.beta, cv.mm, cv.mv, cv.scale, cv.shift, cv.smean, cv.sinv,
                         training=tr)
@@ -416,7 +424,9 @@ class Network:
                 on_layer_done(ld)
             i -= 1
         dy0 = self._bwd_bn(A, 0, g)
-        ops.stem_wgrad(A["image"], dy0, Lr[0].dw)
+        self._stem_dw.zero_()
+        ops.conv_wgrad(A["im2col"], dy0, self._stem_dw, 1, 1)
+        Lr[0].dw.view(32, 27).add_(self._stem_dw.view(32, 32)[:, :27])
         if on_layer_done:
             on_layer_done(0)
 

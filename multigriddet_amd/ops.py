@@ -65,8 +65,9 @@ def taps_dgrad_s2(ph, pw):
 class PackedConv:
     """Packed bf16 images of one conv's weights: forward + data-gradient variants."""
 
-    def __init__(self, co, ci, k, s, device, need_dgrad=True):
+    def __init__(self, co, ci, k, s, device, need_dgrad=True, ci_master=None):
         self.co, self.ci, self.k, self.s = co, ci, k, s
+        self.ci_master = ci if ci_master is None else ci_master    # channels of the fp32 master (stem: 27 of 32)
         T = k * k
         self.T = T
         self.fwd_kpad = _ru(T * ci, 64)
@@ -90,12 +91,51 @@ class PackedConv:
         """w: fp32 [Co, T, Ci] master weights -> rewrite the packed images."""
         lib = L.load()
         src = (C.c_int32 * 9)(*range(self.T), *([0] * (9 - self.T)))
-        L.check(lib.mgd_pack_weights(L.ptr(w), L.ptr(self.fwd), self.co, self.T, self.ci, 0, self.T, src,
+        L.check(lib.mgd_pack_weights(L.ptr(w), L.ptr(self.fwd), self.co, self.T, self.ci_master, 0, self.T, src,
                                      self.fwd_copad, self.fwd_kpad, L.stream_ptr()), "pack fwd")
         for img, kp, cp, st, _ in self.dgrad:
             src = (C.c_int32 * 9)(*st, *([0] * (9 - len(st))))
-            L.check(lib.mgd_pack_weights(L.ptr(w), L.ptr(img), self.co, self.T, self.ci, 1, len(st), src, cp, kp,
+            L.check(lib.mgd_pack_weights(L.ptr(w), L.ptr(img), self.co, self.T, self.ci_master, 1, len(st), src, cp, kp,
                                          L.stream_ptr()), "pack dgrad")
+
+
+class PackBatch:
+    """All packed images of a list of (PackedConv, master weight view) in one launch."""
+
+    def __init__(self, pairs, device):
+        jobs = []
+        begin = 0
+        for pk, w in pairs:
+            imgs = [(pk.fwd, 0, pk.T, list(range(pk.T)), pk.fwd_copad, pk.fwd_kpad)]
+            for img, kp, cp, st, _ in pk.dgrad:
+                imgs.append((img, 1, len(st), st, cp, kp))
+            for img, tr, nt, st, rows_pad, kpad in imgs:
+                j = L.PackJob()
+                j.w, j.out = w.data_ptr(), img.data_ptr()
+                j.Co, j.T, j.Ci, j.transpose, j.ntaps_out = pk.co, pk.T, pk.ci_master, tr, nt
+                j.rows_pad, j.K_pad = rows_pad, kpad
+                code = 0
+                for t, sidx in enumerate(st):
+                    code |= int(sidx) << (4 * t)
+                j.srccode, j.begin = code, begin
+                begin += rows_pad * kpad
+                jobs.append(j)
+        self.n, self.total = len(jobs), begin
+        arr = (L.PackJob * len(jobs))(*jobs)
+        raw = bytes(arr)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+    def run(self):
+        L.check(L.load().mgd_pack_weights_batch(L.ptr(self.table), self.n, C.c_int64(self.total), L.stream_ptr()),
+                "pack_batch")
+
+
+def stem_im2col(image, out=None):
+    N, H, W, _ = image.shape
+    if out is None:
+        out = torch.empty(N, H, W, 32, dtype=torch.bfloat16, device=image.device)
+    L.check(L.load().mgd_stem_im2col(L.ptr(image), L.ptr(out), N, H, W, L.stream_ptr()), "stem_im2col")
+    return out
 
 
 def _desc(src, wpk, dst, N, Hs, Ws, Ci, Hg, Wg, Hd, Wd, Co, in_stride, out_stride, off, dh, dw, K_pad, Co_pad,

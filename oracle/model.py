@@ -87,8 +87,10 @@ def conv_bn_leaky(x, p, sp, training, stats_out=None, emulate_bf16=False, residu
     where the gfx950 path stores bf16 (fp32 accumulation in between), so that the comparison with the
     product isolates logic errors from bf16 storage noise."""
     w = p["kernel"].permute(3, 2, 0, 1)                     # (kh,kw,cin,cout) -> OIHW
-    if emulate_bf16 and sp["cin"] != 3:
+    if emulate_bf16:
         w = _bf16(w)
+        if sp["cin"] == 3:
+            x = _bf16(x)            # the product's stem consumes a bf16 im2col image
     if sp["s"] == 2:
         x = F.pad(x, (1, 0, 1, 0))                            # left, right, top, bottom: top/left only
         y = F.conv2d(x, w, stride=2)
