@@ -55,9 +55,9 @@ def mixup(images, boxes, partner, lam, M_out=None):
     dev = images.device
     out_i = torch.empty_like(images)
     out_b = torch.empty(B, M_out, 5, dtype=torch.float32, device=dev)
-    L.check(L.load().mgd_mixup(L.ptr(images), L.ptr(boxes), B, S, M_in, L.ptr(torch.from_numpy(partner).to(dev)),
-                               L.ptr(torch.from_numpy(lam).to(dev)), L.ptr(out_i), L.ptr(out_b), M_out,
-                               L.stream_ptr()), "mixup")
+    pd, ld = torch.from_numpy(partner).to(dev), torch.from_numpy(lam).to(dev)   # keep alive across the call
+    L.check(L.load().mgd_mixup(L.ptr(images), L.ptr(boxes), B, S, M_in, L.ptr(pd), L.ptr(ld), L.ptr(out_i),
+                               L.ptr(out_b), M_out, L.stream_ptr()), "mixup")
     return out_i, out_b
 
 
@@ -73,7 +73,7 @@ def gridmask(images, boxes, apply, params, keep_frac=0.3):
     """In place on images in the [0,255] range and on the box list (kept boxes compacted to the front)."""
     B, S = images.shape[0], images.shape[1]
     dev = images.device
-    L.check(L.load().mgd_gridmask(L.ptr(images), L.ptr(boxes), B, S, boxes.shape[1],
-                                  L.ptr(torch.from_numpy(apply).to(dev)), L.ptr(torch.from_numpy(params).to(dev)),
+    ad, pd = torch.from_numpy(apply).to(dev), torch.from_numpy(params).to(dev)   # keep alive across the call
+    L.check(L.load().mgd_gridmask(L.ptr(images), L.ptr(boxes), B, S, boxes.shape[1], L.ptr(ad), L.ptr(pd),
                                   C.c_float(keep_frac), L.stream_ptr()), "gridmask")
     return images, boxes
