@@ -99,7 +99,9 @@ int mgd_pack_weights(const float* w, void* out, int Co, int T, int Ci, int trans
                      const int32_t* src_tap_host, int rows_pad, int K_pad, void* stream);
 
 /* All packed images of a network in ONE launch: `jobs_dev` is a device array of njobs descriptors sorted by
- * `begin` (flat element index of the job's first output element); total = sum of rows_pad*K_pad. */
+ * `begin` = index of the job's first 32x32 tile, a job having ntaps_out * ceil(cin/32) * ceil(rows/32) tiles
+ * (rows, cin = Co, Ci or swapped when transpose); total = number of tiles.  Only the valid region of each
+ * image is written: the caller zero-fills the images once at allocation. */
 typedef struct mgd_pack_job {
   const float* w;      /* fp32 master weights [Co][T][Ci]          */
   void* out;           /* bf16 image [rows_pad][K_pad]             */
@@ -128,6 +130,11 @@ int mgd_bn_finalize(const float* stats, int replicas, int C, float count, const 
 /* a = leaky(y*scale+shift) (+ residual); bf16 [P][C] */
 int mgd_bn_act_fwd(const void* y, const float* scale, const float* shift, const void* residual, void* a,
                    int64_t P, int C, float slope, void* stream);
+/* mgd_bn_finalize + mgd_bn_act_fwd in one launch (every block folds the replicas of its channel window). */
+int mgd_bn_act_fwd_fused(const float* stats, int replicas, float count, const float* gamma, const float* beta,
+                         float* moving_mean, float* moving_var, float* scale, float* shift, float* save_mean,
+                         float* save_invstd, float eps, float momentum, int training, const void* y,
+                         const void* residual, void* a, int64_t P, int C, float slope, void* stream);
 /* sums[R][2][C] += { sum dyh, sum dyh*yhat },  dyh = da * leaky'(y*scale+shift) */
 int mgd_bn_act_bwd_reduce(const void* da, const void* y, const float* scale, const float* shift,
                           const float* save_mean, const float* save_invstd, float* sums, int replicas,
@@ -147,6 +154,9 @@ int mgd_upsample_concat_bwd(const void* dout, void* du, void* dskip, int N, int 
 int mgd_bias_grad(const void* dy_bf16, float* dbias, int64_t P, int C, void* stream);
 int mgd_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int mgd_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
+
+/* diagnostic: phase-stamp sums of the stamped gather-GEMM build (MGD_DBG=2), cleared on read; out_host[8]. */
+int mgd_debug_read_stamps(unsigned long long* out_host);
 
 /* Adam with Keras semantics (config/model_builder.py:86-96): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
  * p -= lr_t*m/(sqrt(v)+eps).  grad_scale multiplies g first (1/world for DP averaging).

@@ -35,7 +35,8 @@ struct GemmArgs {
   int M;        // N*Hg*Wg
   int tilesC;   // Co_pad / BNC
   int nblk;
-  int dbg;      // diagnostic only (MGD_DBG): 1 = all LDS-DMA loads hit one cache line
+  int dbg;      // diagnostic only (MGD_DBG): 1 = all LDS-DMA loads hit one cache line, 2 = phase stamps
+  unsigned long long* stamps;
 };
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * ROWB + ((kc ^ (row & 7)) << 4); }
@@ -280,7 +281,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WC, int WP, int MT, int NT, int NST>
+template <int WC, int WP, int MT, int NT, int NST, bool STAMP = false>
 __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
   constexpr int BNC = WC * MT * 16;
   constexpr int BMP = WP * NT * 16;
@@ -407,6 +408,284 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
   for (int n = 0; n < NT; ++n) xro[n] = BNC * ROWB + lds_off((wp * NT + n) * 16 + fr, fq);
   const int zslot = BNC * ROWB + (rlo * ROWB) + (tid & 7) * 16;   // + i * RPR*ROWB : my X slots
 
+  // diagnostic build only (STAMP): cycles per phase of the K-loop, summed per wave, one atomic per wave at
+  // the end into a.stamps[0..4] = {wait vmcnt, zero-fix + barrier, LDS-DMA issue, fragment reads + MFMA, loops}
+  unsigned long long tw = 0, tb = 0, ti = 0, tcomp = 0, t0 = 0, t1 = 0;
+  auto stamp = [&]() -> unsigned long long {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+  };
+  for (int ks = 0; ks < nk; ++ks) {
+    if (STAMP) { __builtin_amdgcn_sched_barrier(0); t0 = stamp(); __builtin_amdgcn_sched_barrier(0); }
+    int pending = min(NST - 2, nk - 1 - ks);
+    if (NST >= 4 && pending >= 2) wait_vmcnt<2 * LPS>();
+    else if (NST >= 3 && pending == 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp(); tw += t1 - t0; __builtin_amdgcn_sched_barrier(0); }
+    const int cur = ks % NST;
+    unsigned char* sb = smem + cur * STAGE;
+    unsigned invc = 0;
+#pragma unroll
+    for (int s = 0; s < NST; ++s)
+      if (s == cur) invc = inv[s];
+    if (invc) {
+#pragma unroll
+      for (int i = 0; i < XCH; ++i)
+        if (invc & (1u << i)) *(uint4*)(sb + zslot + i * (RPR * ROWB)) = make_uint4(0, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (STAMP) { __builtin_amdgcn_sched_barrier(0); t0 = stamp(); tb += t0 - t1; __builtin_amdgcn_sched_barrier(0); }
+    if (ks + NST - 1 < nk) {
+      issue(ks + NST - 1, (ks + NST - 1) % NST);
+#pragma unroll
+      for (int s = 0; s < NST; ++s)
+        if (s == (ks + NST - 1) % NST) inv[s] = inv_next;
+    }
+    if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp(); ti += t1 - t0; __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 wf[MT], xf[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(sb + (wro[m] ^ (kk << 6)));
+#pragma unroll
+      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + (xro[n] ^ (kk << 6)));
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
+    }
+    if (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+      t0 = stamp(); tcomp += t0 - t1;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (STAMP && a.stamps && lane == 0) {
+    atomicAdd(a.stamps + 0, tw); atomicAdd(a.stamps + 1, tb); atomicAdd(a.stamps + 2, ti); atomicAdd(a.stamps + 3, tcomp);
+    atomicAdd(a.stamps + 4, (unsigned long long)nk);
+  }
+  __syncthreads();
+
+  // ---- epilogue (same as v1)
+  const int esz = a.dst_f32 ? 4 : 2;
+  const int EROW = BNC * esz + 16;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    int cl = (wc * MT + m) * 16 + fq * 4;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (a.bias) {
+      int c = co0 + cl;
+      if (c + 3 < a.Co) { b0 = a.bias[c]; b1 = a.bias[c + 1]; b2 = a.bias[c + 2]; b3 = a.bias[c + 3]; }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      int pl = (wp * NT + n) * 16 + fr;
+      f32x4 v = acc[m][n];
+      v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+      if (a.dst_f32) {
+        *(f32x4*)(smem + pl * EROW + cl * 4) = v;
+      } else {
+        uint2 p;
+        p.x = pack2bf(v[0], v[1]);
+        p.y = pack2bf(v[2], v[3]);
+        *(uint2*)(smem + pl * EROW + cl * 2) = p;
+      }
+    }
+  }
+  __syncthreads();
+  const int rows_valid = min(BMP, a.M - pix0);
+  if (a.stats && !a.dst_f32) {
+    constexpr int NCP = BNC / 2, RG = NTHR / NCP, RPG = BMP / RG;
+    if (tid < 2 * BNC) colred[tid] = 0.f;
+    __syncthreads();
+    int cp = tid % NCP, rg = tid / NCP;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    int rend = min(rows_valid, (rg + 1) * RPG);
+    for (int r = rg * RPG; r < rend; ++r) {
+      uint32_t u = *(const uint32_t*)(smem + r * EROW + cp * 4);
+      float v0 = __uint_as_float(u << 16), v1 = __uint_as_float(u & 0xffff0000u);
+      s0 += v0; s1 += v1; q0 += v0 * v0; q1 += v1 * v1;
+    }
+    atomicAdd(&colred[2 * cp], s0);
+    atomicAdd(&colred[2 * cp + 1], s1);
+    atomicAdd(&colred[BNC + 2 * cp], q0);
+    atomicAdd(&colred[BNC + 2 * cp + 1], q1);
+    __syncthreads();
+    if (tid < 2 * BNC) {
+      int which = tid / BNC, col = tid - which * BNC;
+      if (co0 + col < a.Co) {
+        int rep = blockIdx.x % a.stats_replicas;
+        atomicAdd(a.stats + ((long long)rep * 2 + which) * a.Co + co0 + col, colred[tid]);
+      }
+    }
+  }
+  const int CPR = BNC * esz / 16;
+  for (int q = tid; q < BMP * CPR; q += NTHR) {
+    int r = q / CPR, ch = q - r * CPR;
+    long long off = row_dst[r];
+    int c = co0 + ch * (16 / esz);
+    if (off < 0 || c >= a.Co) continue;
+    uint4 v = *(const uint4*)(smem + r * EROW + ch * 16);
+    if (a.dst_f32) {
+      *(uint4*)((float*)a.dst + off + c) = v;
+    } else {
+      if (a.addend) {
+        uint4 ad = *(const uint4*)(a.addend + off + c);
+        float f[8], g[8];
+        unpack8(v, f);
+        unpack8(ad, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += g[j];
+        v = pack8(f);
+      }
+      *(uint4*)((bf16_t*)a.dst + off + c) = v;
+    }
+  }
+}
+
+template <int WC, int WP, int MT, int NT, int NST>
+__global__ __launch_bounds__(64 * WC * WP) void conv_gemm3_kernel(GemmArgs a) {
+  // BK = 32 variant: tile rows are 64 B (4 chunks of 16 B), chunk c of row r stored at slot c ^ g((r>>2)&3)
+  // with g = {0,3,2,1} (conflict-free ds_read_b128 for the 16x16x32 fragment pattern); one LDS-DMA
+  // wave-instruction covers 16 rows.  Bigger block tile (256 pixels) and 128x64 wave tiles cut the
+  // LDS-DMA bytes per FLOP by 25 % and the fragment reads per MFMA from 16/32 to 12/32.
+  constexpr int BK = 32;
+  constexpr int ROWB = 64;
+  constexpr int BNC = WC * MT * 16;
+  constexpr int BMP = WP * NT * 16;
+  constexpr int NTHR = 64 * WC * WP;      // 4 waves (128-pixel tile, 2 blocks/CU) or 8 waves (256-pixel tile)
+  constexpr int RPR = NTHR / 4;            // tile rows covered by one LDS-DMA round of the block
+  static_assert(BMP % RPR == 0 && BNC % RPR == 0, "tile/threads");
+  constexpr int WCH = BNC / RPR;  // weight glds per thread per stage
+  constexpr int XCH = BMP / RPR;  // pixel glds per thread per stage
+  constexpr int LPS = WCH + XCH;  // loads per stage per wave
+  constexpr int STAGE = (BNC + BMP) * ROWB;
+  constexpr int EPI_MAX = BMP * (BNC * 2 + 16);    // bf16 epilogue tile only (fp32 output is not dispatched here)
+  constexpr int AUX = NST * STAGE > EPI_MAX ? NST * STAGE : EPI_MAX;   // then row_dst (BMP x 8 B) + colred (256 x 4 B)
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  long long* row_dst = (long long*)(smem + AUX);
+  float* colred = (float*)(smem + AUX + BMP * 8);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wc = wave / WP, wp = wave % WP;
+
+  const int L = xcd_remap(blockIdx.x, a.nblk);
+  const int tc = L % a.tilesC, tp = L / a.tilesC;
+  const int co0 = tc * BNC;
+  const int pix0 = tp * BMP;
+
+  if (tid < BMP) {
+    int m = pix0 + tid;
+    long long off = -1;
+    if (m < a.M) {
+      int hw = a.Hg * a.Wg;
+      int n = m / hw, rem = m - n * hw;
+      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+      int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
+      off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
+    }
+    row_dst[tid] = off;
+  }
+
+  // thread -> LDS slot (tid & 7) of rows (tid >> 3) + RPR i ; source chunk kc = slot ^ (row & 7).
+  // Address generation is kept off the critical path (the first version spent 5.7 VALU instructions
+  // per MFMA on it): per row a 32-bit byte offset and a 9-bit tap-validity mask are computed once; per
+  // K-step a load costs a mask test, a select and an add, with the tensor base in SGPRs.  Out-of-image
+  // taps load from offset 0 (any valid address) and the owning lane overwrites its 16-byte LDS slot
+  // with zeros once its own DMA has landed (before the barrier that publishes the stage).
+  const int rlo = tid >> 2;
+  const int kc = (tid & 3) ^ ((4 - ((rlo >> 2) & 3)) & 3);
+  unsigned xoff[XCH];
+  unsigned vmask[XCH];
+#pragma unroll
+  for (int i = 0; i < XCH; ++i) {
+    int m = pix0 + rlo + RPR * i;
+    xoff[i] = 0;
+    vmask[i] = 0;
+    if (m < a.M) {
+      int hw = a.Hg * a.Wg;
+      int n = m / hw, rem = m - n * hw;
+      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+      int hs = ig * a.in_stride, ws = jg * a.in_stride;
+      xoff[i] = (unsigned)(((((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci) * 2);
+      for (int t = 0; t < a.ntaps; ++t) {
+        int dh = (int)((a.tapcode >> (4 * t)) & 3) - 1, dw = (int)((a.tapcode >> (4 * t + 2)) & 3) - 1;
+        if ((unsigned)(hs + dh) < (unsigned)a.Hs && (unsigned)(ws + dw) < (unsigned)a.Ws) vmask[i] |= 1u << t;
+      }
+    }
+  }
+  int tap = (kc * 8) / a.Ci;
+  int cch = (kc * 8) - tap * a.Ci;
+  unsigned woff[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) woff[i] = (unsigned)(((long long)(co0 + rlo + RPR * i) * a.K_pad + kc * 8) * 2);
+  const char* xbase = (const char*)a.src;
+  const char* wbase = (const char*)a.wpk;
+  // my LDS slots (byte offsets inside a stage) for the zero fix-up
+
+  unsigned inv_next = 0;
+  auto issue = [&](int ks, int buf) {
+    unsigned char* wb = smem + buf * STAGE + wave * 1024;          // 16 rows x 64 B per wave-instruction
+    unsigned char* xb = smem + buf * STAGE + BNC * ROWB + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < WCH; ++i)
+      glds16(wbase + ((a.dbg & 1) ? 0u : woff[i] + (unsigned)ks * (BK * 2)), wb + i * (RPR * ROWB));
+    int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
+    int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
+    int toff = ((dh * a.Ws + dw) * a.Ci + cch) * 2;
+    inv_next = 0;
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      bool v = (vmask[i] >> tap) & 1u;
+      unsigned off = v ? xoff[i] + (unsigned)toff : 0u;
+      if (a.dbg & 1) off = 0u;
+      if (!v) inv_next |= 1u << i;
+      glds16(xbase + off, xb + i * (RPR * ROWB));
+    }
+    cch += BK;
+    while (cch >= a.Ci) {
+      cch -= a.Ci;
+      ++tap;
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K_pad / BK;
+  // ring bookkeeping of the zero fix-up masks: stage s issued -> inv[s % NST]
+  unsigned inv[NST];
+#pragma unroll
+  for (int s = 0; s < NST; ++s) inv[s] = 0;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) { issue(s, s); inv[s] = inv_next; }
+
+  const int fr = lane & 15, fq = lane >> 4;
+  // fragment read offsets inside a stage (k-half kk flips bit 6 of the byte offset)
+  int wro[MT], xro[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    int r = (wc * MT + m) * 16 + fr;
+    wro[m] = r * ROWB + ((fq ^ ((4 - ((r >> 2) & 3)) & 3)) << 4);
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    int r = (wp * NT + n) * 16 + fr;
+    xro[n] = BNC * ROWB + r * ROWB + ((fq ^ ((4 - ((r >> 2) & 3)) & 3)) << 4);
+  }
+  const int zslot = BNC * ROWB + (rlo * ROWB) + (tid & 3) * 16;   // + i * RPR*ROWB : my X slots
+
   for (int ks = 0; ks < nk; ++ks) {
     int pending = min(NST - 2, nk - 1 - ks);
     if (NST >= 4 && pending >= 2) wait_vmcnt<2 * LPS>();
@@ -431,13 +710,12 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
       for (int s = 0; s < NST; ++s)
         if (s == (ks + NST - 1) % NST) inv[s] = inv_next;
     }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    {
       bf16x8 wf[MT], xf[NT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(sb + (wro[m] ^ (kk << 6)));
+      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(sb + wro[m]);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + (xro[n] ^ (kk << 6)));
+      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + xro[n]);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -523,6 +801,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
     }
   }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradient.  dW[co][tap][ci] += sum_p dy[p][co] * src[p (+) tap][ci]
@@ -988,24 +1267,50 @@ struct PackJob {
   long long begin;   // first flat element index of this job
 };
 
+// One block = one 32 x 32 tile of one packed image (output rows r0.., columns t*cin + c0..); the tile is read
+// along the source's contiguous index (ci for forward images, the OUTPUT-row index for transposed/data-gradient
+// images) and transposed through LDS when needed, so both sides are coalesced.  Only the valid region is
+// written: the zero padding of the images is written once at allocation and never changes.
+// `begin` of a job here = index of its first tile.
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs, long long total) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  __shared__ float tile[32][33];
+  for (long long bt = blockIdx.x; bt < total; bt += gridDim.x) {
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {
       int mid = (lo + hi + 1) >> 1;
-      if (jobs[mid].begin <= i) lo = mid; else hi = mid - 1;
+      if (jobs[mid].begin <= bt) lo = mid; else hi = mid - 1;
     }
     const PackJob J = jobs[lo];
-    long long e = i - J.begin;
-    int r = (int)(e / J.K_pad), k = (int)(e - (long long)r * J.K_pad);
-    int rows = J.transpose ? J.Ci : J.Co, cin = J.transpose ? J.Co : J.Ci;
-    float v = 0.f;
-    if (r < rows && k < J.ntaps_out * cin) {
-      int t = k / cin, c = k - t * cin;
-      int st = (int)((J.srccode >> (4 * t)) & 15);
-      v = J.transpose ? J.w[((long long)c * J.T + st) * J.Ci + r] : J.w[((long long)r * J.T + st) * J.Ci + c];
+    const int rows = J.transpose ? J.Ci : J.Co, cin = J.transpose ? J.Co : J.Ci;
+    const int tr = (rows + 31) >> 5, tcn = (cin + 31) >> 5;
+    int e = (int)(bt - J.begin);
+    const int rt = e % tr; e /= tr;
+    const int ct = e % tcn;
+    const int t = e / tcn;
+    const int st = (int)((J.srccode >> (4 * t)) & 15);
+    const int r0 = rt * 32, c0 = ct * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (J.transpose) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int c = c0 + ty + 8 * j, r = r0 + tx;
+        tile[ty + 8 * j][tx] = (c < cin && r < rows) ? J.w[((long long)c * J.T + st) * J.Ci + r] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int r = r0 + ty + 8 * j, c = c0 + tx;
+        if (r < rows && c < cin) J.out[(long long)r * J.K_pad + t * cin + c] = f2bf(tile[tx][ty + 8 * j]);
+      }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int r = r0 + ty + 8 * j, c = c0 + tx;
+        if (r < rows && c < cin)
+          J.out[(long long)r * J.K_pad + t * cin + c] = f2bf(J.w[((long long)r * J.T + st) * J.Ci + c]);
+      }
     }
-    J.out[e] = f2bf(v);
   }
 }
 
@@ -1075,6 +1380,40 @@ int launch_gemm2(GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
+
+template <int WC, int WP, int MT, int NT, int NST>
+int launch_gemm3(GemmArgs& a, hipStream_t st) {
+  constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
+  a.tilesC = a.Co_pad / BNC;
+  int tilesP = cdiv(a.M, BMP);
+  a.nblk = a.tilesC * tilesP;
+  size_t ring = (size_t)NST * (BNC + BMP) * 64;
+  size_t epi = (size_t)BMP * (BNC * 2 + 16);
+  ring = (ring > epi ? ring : epi) + (size_t)BMP * 8 + 1024;
+  auto k = conv_gemm3_kernel<WC, WP, MT, NT, NST>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(64 * WC * WP), ring, st, a);
+  return 0;
+}
+
+__device__ unsigned long long g_stamps[8];
+int launch_gemm2_stamped(GemmArgs& a, hipStream_t st) {
+  constexpr int BNC = 128, BMP = 128, NST = 2;
+  a.tilesC = a.Co_pad / BNC;
+  a.nblk = a.tilesC * cdiv(a.M, BMP);
+  size_t ring = (size_t)NST * (BNC + BMP) * ROWB, epi = (size_t)BMP * (BNC * 4 + 16);
+  ring = (ring > epi ? ring : epi) + (size_t)BMP * 8 + 1024;
+  auto k = conv_gemm2_kernel<2, 2, 4, 4, 2, true>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipGetSymbolAddress((void**)&a.stamps, HIP_SYMBOL(g_stamps));
+  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), ring, st, a);
+  return 0;
+}
+
 template <int WC, int WI, int MT, int NT>
 int launch_wgrad(WgradArgs& a, hipStream_t st) {
   constexpr int BCO = WC * MT * 16, BCI = WI * NT * 16;
@@ -1128,6 +1467,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("MGD_DBG"); dbg = e ? atoi(e) : 0; }
   a.dbg = dbg;
+  a.stamps = nullptr;
   hipStream_t st = (hipStream_t)stream;
   static int variant = -1;
   if (variant < 0) {
@@ -1139,13 +1479,17 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     if (d->Co_pad % 128 == 0) launch_gemm<2, 2, 4, 4>(a, st);
     else if (d->Co_pad % 64 == 0) launch_gemm<1, 4, 4, 2>(a, st);
     else launch_gemm<1, 4, 2, 2>(a, st);
+  } else if (variant == 6 && d->Co_pad % 128 == 0 && !d->dst_f32 && (long long)a.M * (d->Co_pad / 128) >= 256ll * 400) {
+    launch_gemm3<2, 2, 4, 8, 3>(a, st);      // 128 cout x 256 pixels, 128x64 wave tiles, BK = 32, 3-stage ring
   } else if (variant == 5 && d->Co_pad % 64 == 0 && (long long)a.M * (d->Co_pad / (d->Co_pad % 128 == 0 ? 128 : 64)) >= 256ll * 200 && !d->dst_f32) {
     // 8-wave, 256-pixel tile, 3-stage ring (1 block/CU): enough tiles to fill the chip
     if (d->Co_pad % 128 == 0) launch_gemm2<2, 4, 4, 4, 3>(a, st); else launch_gemm2<1, 8, 4, 2, 3>(a, st);
   } else {
     const bool deep = (variant == 2) ? nk >= 6 : (variant == 4);
     if (d->Co_pad % 128 == 0) {
-      if (deep) launch_gemm2<2, 2, 4, 4, 4>(a, st); else launch_gemm2<2, 2, 4, 4, 2>(a, st);
+      if (deep) launch_gemm2<2, 2, 4, 4, 4>(a, st);
+      else if (a.dbg & 2) launch_gemm2_stamped(a, st);
+      else launch_gemm2<2, 2, 4, 4, 2>(a, st);
     } else if (d->Co_pad % 64 == 0) {
       if (deep) launch_gemm2<1, 4, 4, 2, 4>(a, st); else launch_gemm2<1, 4, 4, 2, 2>(a, st);
     } else {
@@ -1239,10 +1583,19 @@ extern "C" int mgd_stem_im2col(const float* image, void* out, int N, int H, int 
 extern "C" int mgd_pack_weights_batch(const mgd_pack_job* jobs_dev, int njobs, int64_t total, void* stream) {
   MGD_REQUIRE(jobs_dev && njobs >= 1 && total >= 1, "pack_batch: bad arguments");
   static_assert(sizeof(mgd_pack_job) == sizeof(PackJob), "mgd_pack_job layout");
-  long long g = (total + 255) / 256;
-  if (g > 8192) g = 8192;
+  long long g = total;               // total = number of 32x32 tiles over all jobs
+  if (g > 256 * 64) g = 256 * 64;
   hipLaunchKernelGGL(pack_batch_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs_dev, njobs,
                      (long long)total);
   MGD_CHECK_LAUNCH("pack_batch");
+  return MGD_OK;
+}
+
+// diagnostic: read and clear the phase-stamp sums of the stamped gemm build (MGD_DBG=2)
+extern "C" int mgd_debug_read_stamps(unsigned long long* out_host) {
+  unsigned long long* dptr = nullptr;
+  if (hipGetSymbolAddress((void**)&dptr, HIP_SYMBOL(g_stamps)) != hipSuccess) return MGD_ELAUNCH;
+  if (hipMemcpy(out_host, dptr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return MGD_ELAUNCH;
+  (void)hipMemset(dptr, 0, 8 * sizeof(unsigned long long));
   return MGD_OK;
 }

@@ -68,6 +68,100 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
   }
 }
 
+
+// Fused BatchNorm finalize + apply + LeakyReLU (+ residual): every block folds the R statistic replicas of
+// its <= 256-channel window (thread t <-> channel), block x == 0 also publishes scale/shift/mean/invstd for
+// the backward pass and updates the moving statistics.  Saves one launch per BN layer (66 per step).
+__global__ __launch_bounds__(256) void bn_act_fwd_fused_kernel(const float* __restrict__ stats, int R, float count,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* mm, float* mv,
+                                                               float* scale, float* shift, float* smean, float* sinv,
+                                                               float eps, float mom, int training,
+                                                               const bf16_t* __restrict__ y, const bf16_t* res,
+                                                               bf16_t* __restrict__ a, long long P, int C, float slope) {
+  __shared__ float prm[2][256];
+  const int CV = C >> 3;
+  const int CVB = CV < 32 ? CV : 32;
+  const int PL = 256 / CVB;
+  {
+    int c = blockIdx.y * 256 + threadIdx.x;
+    float sc = 0.f, sh = 0.f;
+    if (c < C && threadIdx.x < CVB * 8) {
+      float mean, var;
+      if (training) {
+        float s = 0.f, q = 0.f;
+        for (int r = 0; r < R; ++r) {
+          s += stats[((long long)r * 2 + 0) * C + c];
+          q += stats[((long long)r * 2 + 1) * C + c];
+        }
+        mean = s / count;
+        var = fmaxf(q / count - mean * mean, 0.f);
+      } else {
+        mean = mm[c];
+        var = mv[c];
+      }
+      float inv = 1.0f / sqrtf(var + eps);
+      sc = gamma[c] * inv;
+      sh = beta[c] - mean * sc;
+      if (blockIdx.x == 0) {
+        scale[c] = sc; shift[c] = sh;
+        if (smean) smean[c] = mean;
+        if (sinv) sinv[c] = inv;
+        if (training) {
+          if (mm) mm[c] = mm[c] * mom + mean * (1.f - mom);
+          if (mv) mv[c] = mv[c] * mom + var * (1.f - mom);
+        }
+      }
+    }
+    prm[0][threadIdx.x] = sc;
+    prm[1][threadIdx.x] = sh;
+  }
+  __syncthreads();
+  const int oct = blockIdx.y * 32 + (threadIdx.x % CVB);
+  const int pl = threadIdx.x / CVB;
+  if (!(oct < CV && pl < PL)) return;
+  float sc[8], sh[8];
+  {
+    int lo = (threadIdx.x % CVB) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = prm[0][lo + j]; sh[j] = prm[1][lo + j]; }
+  }
+  constexpr int U = 4;
+  const long long stride = (long long)gridDim.x * PL;
+  for (long long p0 = (long long)blockIdx.x * PL + pl; p0 < P; p0 += stride * U) {
+    uint4 yv[U], rv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long long p = p0 + u * stride;
+      if (p < P) {
+        long long e = p * C + oct * 8;
+        yv[u] = *(const uint4*)(y + e);
+        if (res) rv[u] = *(const uint4*)(res + e);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long long p = p0 + u * stride;
+      if (p < P) {
+        float f[8];
+        unpack8(yv[u], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float z = fmaf(f[j], sc[j], sh[j]);
+          f[j] = z > 0.f ? z : z * slope;
+        }
+        if (res) {
+          float g[8];
+          unpack8(rv[u], g);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] += g[j];
+        }
+        *(uint4*)(a + p * C + oct * 8) = pack8(f);
+      }
+    }
+  }
+}
+
 // BN + LeakyReLU backward, two passes over (da, y):
 //   REDUCE: per-channel sums of dyh = da * leaky'(z) and dyh * yhat  -> sums[R][2][C] (atomics, R replicas)
 //   APPLY : dy = scale * (dyh - mean(dyh) - yhat * mean(dyh * yhat)); block 0 of each channel window also
@@ -397,6 +491,25 @@ extern "C" int mgd_bn_act_bwd_apply(const void* da, const void* y, const float* 
                      (const bf16_t*)y, scale, shift, save_mean, save_invstd, (float*)sums, replicas, dgamma, dbeta,
                      (bf16_t*)dy, (long long)P, C, slope, frozen);
   MGD_CHECK_LAUNCH("bn_act_bwd_apply");
+  return MGD_OK;
+}
+
+
+extern "C" int mgd_bn_act_fwd_fused(const float* stats, int replicas, float count, const float* gamma,
+                                    const float* beta, float* moving_mean, float* moving_var, float* scale,
+                                    float* shift, float* save_mean, float* save_invstd, float eps, float momentum,
+                                    int training, const void* y, const void* residual, void* a, int64_t P, int C,
+                                    float slope, void* stream) {
+  MGD_REQUIRE(gamma && beta && scale && shift && y && a, "bn_act_fwd_fused: null pointer");
+  MGD_REQUIRE(C % 8 == 0, "bn_act_fwd_fused: C=%d must be a multiple of 8", C);
+  MGD_REQUIRE(training ? (stats != nullptr && replicas >= 1 && count > 0) : (moving_mean && moving_var),
+              "bn_act_fwd_fused: missing statistics");
+  int gx, gy;
+  bn_bwd_grid(P, C, &gx, &gy);
+  hipLaunchKernelGGL(bn_act_fwd_fused_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, stats, replicas, count,
+                     gamma, beta, moving_mean, moving_var, scale, shift, save_mean, save_invstd, eps, momentum, training,
+                     (const bf16_t*)y, (const bf16_t*)residual, (bf16_t*)a, (long long)P, C, slope);
+  MGD_CHECK_LAUNCH("bn_act_fwd_fused");
   return MGD_OK;
 }
 

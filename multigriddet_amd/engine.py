@@ -264,9 +264,8 @@ class Network:
             x = ops.stem_im2col(x, out=A["im2col"])
         ops.conv_fwd(x, cv.pk, out=y, stats=cv.stats if tr else None)
         P = y.numel() // cv.cout
-        ops.bn_finalize(cv.stats, float(P), cv.gamma, cv.beta, cv.mm, cv.mv, cv.scale, cv.shift, cv.smean, cv.sinv,
-                        training=tr)
-        return ops.bn_act_fwd(y, cv.scale, cv.shift, A["a"][i], residual=residual)
+        return ops.bn_act_fwd_fused(cv.stats, float(P), cv.gamma, cv.beta, cv.mm, cv.mv, cv.scale, cv.shift,
+                                    cv.smean, cv.sinv, y, A["a"][i], residual=residual, training=tr)
 
     def forward(self, images):
         """images: fp32 CUDA [B,H,W,3] in [0,1].  Returns [y1, y2, y3] raw head tensors (fp32 NHWC)."""

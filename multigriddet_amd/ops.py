@@ -118,7 +118,8 @@ class PackBatch:
                 for t, sidx in enumerate(st):
                     code |= int(sidx) << (4 * t)
                 j.srccode, j.begin = code, begin
-                begin += rows_pad * kpad
+                rows, cin = (pk.ci_master, pk.co) if tr else (pk.co, pk.ci_master)
+                begin += nt * (-(-cin // 32)) * (-(-rows // 32))      # 32x32 tiles of the valid region
                 jobs.append(j)
         self.n, self.total = len(jobs), begin
         arr = (L.PackJob * len(jobs))(*jobs)
@@ -250,6 +251,19 @@ def bn_act_fwd(y, scale, shift, out, residual=None):
     P = y.numel() // Cn
     L.check(L.load().mgd_bn_act_fwd(L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(residual), L.ptr(out),
                                     C.c_int64(P), Cn, C.c_float(LEAKY_SLOPE), L.stream_ptr()), "bn_act_fwd")
+    return out
+
+
+def bn_act_fwd_fused(stats, count, gamma, beta, mm, mv, scale, shift, smean, sinv, y, out, residual=None,
+                     training=True):
+    """bn_finalize + bn_act_fwd in one launch."""
+    Cn = y.shape[-1]
+    P = y.numel() // Cn
+    L.check(L.load().mgd_bn_act_fwd_fused(L.ptr(stats), STATS_REPLICAS, C.c_float(count), L.ptr(gamma), L.ptr(beta),
+                                          L.ptr(mm), L.ptr(mv), L.ptr(scale), L.ptr(shift), L.ptr(smean),
+                                          L.ptr(sinv), C.c_float(BN_EPS), C.c_float(BN_MOMENTUM), int(training),
+                                          L.ptr(y), L.ptr(residual), L.ptr(out), C.c_int64(P), Cn,
+                                          C.c_float(LEAKY_SLOPE), L.stream_ptr()), "bn_act_fwd_fused")
     return out
 
 

@@ -179,6 +179,17 @@ def test_bn_act_fwd_bwd(dev, C, P, res):
     np.testing.assert_allclose(mm.cpu().numpy(), 0.01 * mean.detach().numpy(), rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(mv.cpu().numpy(), 0.99 + 0.01 * var.detach().numpy(), rtol=1e-3, atol=1e-5)
 
+    # fused finalize+apply launch must agree with the two-launch path (outputs, saved statistics, moving stats)
+    mm2, mv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    sc2, sh2, sm2, si2 = (torch.empty(C, device=dev) for _ in range(4))
+    out2 = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
+    ops.bn_act_fwd_fused(stats, float(P), gamma.to(dev), beta.to(dev), mm2, mv2, sc2, sh2, sm2, si2, yd, out2,
+                         residual=r.to(dev) if res else None)
+    torch.cuda.synchronize()
+    assert (out2.float() - out.float()).abs().max().item() <= 2e-2
+    for u, v in ((sc2, scale), (sh2, shift), (sm2, smean), (si2, sinv), (mm2, mm), (mv2, mv)):
+        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
     sums = torch.zeros((ops.STATS_REPLICAS + 1) * 2 * C, device=dev)
     dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     dy = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
@@ -188,6 +199,28 @@ def test_bn_act_fwd_bwd(dev, C, P, res):
     np.testing.assert_allclose(dgam.cpu().numpy(), gr.grad.numpy(), rtol=2e-3, atol=5e-2)
     e = (dy.float().cpu() - yr.grad).abs().max().item()
     assert e <= 0.02 * yr.grad.abs().max().item() + 1e-3
+
+
+def test_pack_batch_matches_single_packs(dev):
+    from multigriddet_amd import ops
+    g = torch.Generator().manual_seed(2)
+    pairs, singles = [], []
+    for co, ci, k, s_ in ((64, 32, 3, 2), (88, 704, 1, 1), (176, 64, 3, 1), (32, 27, 1, 1)):
+        if ci == 27:
+            pk = ops.PackedConv(co, 32, 1, 1, dev, need_dgrad=False, ci_master=27)
+            pk2 = ops.PackedConv(co, 32, 1, 1, dev, need_dgrad=False, ci_master=27)
+        else:
+            pk, pk2 = ops.PackedConv(co, ci, k, s_, dev), ops.PackedConv(co, ci, k, s_, dev)
+        w = torch.randn(co, k * k, ci, generator=g).to(dev)
+        pairs.append((pk, w))
+        pk2.refresh(w)
+        singles.append(pk2)
+    ops.PackBatch(pairs, dev).run()
+    torch.cuda.synchronize()
+    for (pk, _), pk2 in zip(pairs, singles):
+        assert torch.equal(pk.fwd.view(torch.int16), pk2.fwd.view(torch.int16))
+        for a, b in zip(pk.dgrad, pk2.dgrad):
+            assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16))
 
 
 def test_upsample_concat(dev):
