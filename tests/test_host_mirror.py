@@ -1,0 +1,91 @@
+"""CPU: host-side mirror of the reference API (no GPU): config semantics, anchors/classes parsing against the
+reference-generated golden file, class weights, LR schedule, the `multigriddet` import shim, CLI flag sets."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def test_shim_and_anchor_parsing_vs_reference_output():
+    import multigriddet
+    from multigriddet.utils import load_anchors, load_classes
+    a = load_anchors(os.path.join(ROOT, "configs", "yolov3_coco_anchor.txt"))
+    g = np.load(os.path.join(GOLDEN, "anchors.npz"))
+    assert len(a) == 3 and all(np.array_equal(x, g[f"a{i}"]) for i, x in enumerate(a))
+    assert len(load_classes(os.path.join(ROOT, "configs", "coco_classes.txt"))) == 80
+    assert multigriddet.list_available_models() == ["multigriddet_darknet"]
+
+
+def test_config_merge_and_validation(tmp_path):
+    from multigriddet_amd.config import ConfigLoader
+    base = {"a": {"x": 1, "y": {"z": 2}}, "b": [1, 2]}
+    over = {"a": {"y": {"z": 3, "w": 4}}, "b": [9]}
+    m = ConfigLoader.merge_configs(base, over)
+    assert m == {"a": {"x": 1, "y": {"z": 3, "w": 4}}, "b": [9]} and base["a"]["y"]["z"] == 2
+    with pytest.raises(FileNotFoundError):
+        ConfigLoader.load_config(str(tmp_path / "nope.yaml"))
+    with pytest.raises(KeyError):
+        ConfigLoader.validate_config({"data": {}}, "training")
+    with pytest.raises(ValueError):
+        ConfigLoader.validate_config({"model_config": "m", "data": {}, "training": {"loss_option": 7}}, "training")
+    r = ConfigLoader.resolve_paths({"p": "x/y.yaml", "q": ["a.txt", 3], "r": "/abs/z.h5", "s": "keep.me"}, str(tmp_path))
+    assert r["p"] == str(tmp_path / "x/y.yaml") and r["q"][0] == str(tmp_path / "a.txt") and r["r"] == "/abs/z.h5"
+    assert r["s"] == "keep.me"
+
+
+def test_optimizer_factory_precedence():
+    from multigriddet_amd.config import create_optimizer_from_config
+    o = create_optimizer_from_config({"optimizer": {"type": "adamw", "learning_rate": 0.5}, "training": {"learning_rate": 0.01}})
+    assert o.kind == "adamw" and float(o.learning_rate) == 0.01 and o.kwargs["weight_decay"] == 0.0005
+    o = create_optimizer_from_config({"optimizer": {"type": "sgd", "learning_rate": 0.2}})
+    assert o.kind == "sgd" and float(o.learning_rate) == 0.2 and o.kwargs["momentum"] == 0.937
+    assert float(create_optimizer_from_config({}).learning_rate) == 0.001
+
+
+def test_class_weights(tmp_path):
+    from multigriddet_amd.utils import compute_class_weights
+    f = tmp_path / "ann.txt"
+    f.write_text("a.jpg 1,2,3,4,0 1,2,3,4,0 1,2,3,4,1\nb.jpg 5,5,9,9,2\nc.jpg\n")
+    w = compute_class_weights(str(f), 4, "balanced")
+    # reference formula: an absent class gets total/(C*1e-8), the mean normalisation then floors the rest at 0.1
+    assert w.dtype == np.float32 and np.allclose(w, [0.1, 0.1, 0.1, 4.0])
+    assert np.array_equal(compute_class_weights(str(tmp_path / "ann.txt"), 4, "other"), np.ones(4, np.float32))
+
+
+def test_cosine_warmup_schedule_values():
+    from multigriddet_amd.trainers import CosineAnnealingWithWarmup
+    s = CosineAnnealingWithWarmup(1e-3, min_lr=1e-7, warmup_epochs=3, total_epochs=100, verbose=0)
+    assert abs(s.lr_at(0) - (1e-5 + (1e-3 - 1e-5) / 3)) < 1e-12          # epoch 1 of warm-up
+    assert abs(s.lr_at(2) - 1e-3) < 1e-12
+    assert abs(s.lr_at(99) - 1e-7) < 1e-10                                # cosine reaches min_lr at the end
+    assert s.lr_at(50) < s.lr_at(10)
+
+
+def test_expansion_factor_contract():
+    """Capacity factors 1/2/4/8 (reference tests/test_augmentation_capacity.py:108-268)."""
+    from multigriddet_amd.data.generators import MultiGridDataGenerator
+    anchors = [np.ones((3, 2))] * 3
+    mk = lambda **k: MultiGridDataGenerator([], 4, (608, 608), anchors, 80, **k)._calculate_expansion_factor()
+    assert mk(enhance_augment="mosaic", mosaic_prob=0.3, mixup_prob=0.1) == 8
+    assert mk(enhance_augment="mosaic", mosaic_prob=0.3, mixup_prob=0.0) == 4
+    assert mk(enhance_augment=None, mixup_prob=0.1) == 2
+    assert mk(enhance_augment=None, mixup_prob=0.0) == 1
+
+
+@pytest.mark.parametrize("script,flags", [("train.py", ["--config", "--weights", "--backbone-weights", "--resume", "--epochs", "--batch-size"]),
+                                          ("infer.py", ["--config", "--input", "--output", "--weights", "--type", "--conf", "--nms", "--no-save", "--no-show"])])
+def test_cli_flags(script, flags):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, script), "--help"], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0
+    for f in flags:
+        assert f in out.stdout
+
+
+def test_cli_missing_config_returns_1():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--config", "/nonexistent.yaml"],
+                         capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 1 and "Config file not found" in out.stdout
