@@ -26,8 +26,9 @@ def make_buckets(layer_offsets, n_params, bucket_elems):
 
 
 class GradBuckets:
-    def __init__(self, grads, layer_offsets, world_size, bucket_mb=32.0, comm_stream=None):
+    def __init__(self, grads, layer_offsets, world_size, bucket_mb=32.0, comm_stream=None, producer_streams=()):
         self.grads = grads
+        self.producer_streams = tuple(producer_streams)     # side streams that also write gradients (wgrad)
         self.world = world_size
         self.buckets = make_buckets(layer_offsets, grads.numel(), int(bucket_mb * 1e6 / 4))
         self.comm_stream = comm_stream
@@ -53,6 +54,8 @@ class GradBuckets:
                 ev = torch.cuda.Event()
                 ev.record()
                 self.comm_stream.wait_event(ev)
+                for ps in self.producer_streams:
+                    self.comm_stream.wait_stream(ps)
                 with torch.cuda.stream(self.comm_stream):
                     self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
             else:

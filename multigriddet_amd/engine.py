@@ -120,6 +120,11 @@ class Network:
         self.freeze_backbone = False
         self.freeze_all_but_pred = False
         self.freeze_bn = False          # every BatchNorm on its moving statistics (convs stay trainable)
+        # Weight gradients are off the critical path of backward (nothing consumes them before the optimiser):
+        # they run on a side stream and fill the CUs that the small / tail-heavy kernels of the dgrad -> BN chain
+        # leave idle.  Needs one dy buffer per layer (no scratch reuse while a side-stream wgrad may read it).
+        self.overlap_wgrad = True
+        self.wg_stream = torch.cuda.Stream(device=dev)
         self._arenas = {}
         self.reset_parameters(seed)
 
@@ -309,10 +314,20 @@ class Network:
         """da: grad wrt the activated output of layer i -> returns dy (grad wrt the raw conv output)."""
         cv = self.layers[i]
         y = A["y"][i]
-        dy = self._scratch(A, "dy", y.shape)
+        dy = self._scratch(A, ("dy", i) if self.overlap_wgrad else "dy", y.shape)
         frozen = not self._bn_training(cv)
         ops.bn_act_bwd(da, y, cv.scale, cv.shift, cv.smean, cv.sinv, cv.sums, cv.dgamma, cv.dbeta, dy, frozen=frozen)
         return dy
+
+    def _wgrad(self, x, dy, dw, k, s):
+        if not self.overlap_wgrad:
+            ops.conv_wgrad(x, dy, dw, k, s)
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self.wg_stream.wait_event(ev)
+        with torch.cuda.stream(self.wg_stream):
+            ops.conv_wgrad(x, dy, dw, k, s)
 
     def backward(self, douts, on_layer_done=None):
         """douts: three bf16 grads wrt the head outputs.  Accumulates into self.grads (zero it first).
@@ -343,7 +358,7 @@ class Network:
             dy5 = douts[sc]
             a4 = acts[c4]
             ops.bias_grad(dy5, pred.dbias)
-            ops.conv_wgrad(a4, dy5, pred.dw, 1, 1)
+            self._wgrad(a4, dy5, pred.dw, 1, 1)
             if on_layer_done and pred_only:
                 on_layer_done(c5)
             if pred_only:
@@ -351,24 +366,24 @@ class Network:
             d_a4 = ops.conv_dgrad(dy5, pred.pk, hw[c4], out=self._scratch(A, "da_a", a4.shape))
             dy4 = self._bwd_bn(A, c4, d_a4)
             xb = acts[c3]
-            ops.conv_wgrad(xb, dy4, Lr[c4].dw, 3, 1)
+            self._wgrad(xb, dy4, Lr[c4].dw, 3, 1)
             d_xb = ops.conv_dgrad(dy4, Lr[c4].pk, hw[c3], out=self._scratch(A, "da_b", xb.shape))
             if sc < 2:
                 c6 = base + 5
                 dy6 = self._bwd_bn(A, c6, d_up[sc])
-                ops.conv_wgrad(xb, dy6, Lr[c6].dw, 1, 1)
+                self._wgrad(xb, dy6, Lr[c6].dw, 1, 1)
                 ops.conv_dgrad(dy6, Lr[c6].pk, hw[c3], out=d_xb, addend=d_xb)
             dy3 = self._bwd_bn(A, c3, d_xb)
             a2 = acts[c2]
-            ops.conv_wgrad(a2, dy3, Lr[c3].dw, 1, 1)
+            self._wgrad(a2, dy3, Lr[c3].dw, 1, 1)
             d_a2 = ops.conv_dgrad(dy3, Lr[c3].pk, hw[c2], out=self._scratch(A, "da_a", a2.shape))
             dy2 = self._bwd_bn(A, c2, d_a2)
             a1 = acts[c1]
-            ops.conv_wgrad(a1, dy2, Lr[c2].dw, 3, 1)
+            self._wgrad(a1, dy2, Lr[c2].dw, 3, 1)
             d_a1 = ops.conv_dgrad(dy2, Lr[c2].pk, hw[c1], out=self._scratch(A, "da_b", a1.shape))
             dy1 = self._bwd_bn(A, c1, d_a1)
             xin = A["cat"][sc - 1] if sc > 0 else acts[BACKBONE_CONVS - 1]
-            ops.conv_wgrad(xin, dy1, Lr[c1].dw, 1, 1)
+            self._wgrad(xin, dy1, Lr[c1].dw, 1, 1)
             if on_layer_done:
                 on_layer_done(c1)
             if sc > 0:
@@ -384,6 +399,7 @@ class Network:
             elif not train_head_only:
                 g_f1 = ops.conv_dgrad(dy1, Lr[c1].pk, hw[c1], out=self._scratch(A, "g5", acts[BACKBONE_CONVS - 1].shape))
         if pred_only or train_head_only:
+            self._join_wgrad()
             if on_layer_done:
                 on_layer_done(0)
             return
@@ -397,10 +413,10 @@ class Network:
                 x_in = inp(l1)
                 dy2 = self._bwd_bn(A, l2, g)                     # residual branch: d a2 = g
                 a1 = acts[l1]
-                ops.conv_wgrad(a1, dy2, Lr[l2].dw, 3, 1)
+                self._wgrad(a1, dy2, Lr[l2].dw, 3, 1)
                 d_a1 = ops.conv_dgrad(dy2, Lr[l2].pk, hw[l1], out=self._scratch(A, "da_a", a1.shape))
                 dy1 = self._bwd_bn(A, l1, d_a1)
-                ops.conv_wgrad(x_in, dy1, Lr[l1].dw, 1, 1)
+                self._wgrad(x_in, dy1, Lr[l1].dw, 1, 1)
                 ops.conv_dgrad(dy1, Lr[l1].pk, hw[l1], out=g, addend=g)      # g <- g + dgrad (in place)
                 if on_layer_done:
                     on_layer_done(l1)
@@ -409,10 +425,10 @@ class Network:
             x_prev = inp(ld)
             dyd = self._bwd_bn(A, ld, g)
             if st == 0:
-                ops.conv_wgrad(x_prev, dyd, Lr[ld].dw, 3, 2)
+                self._wgrad(x_prev, dyd, Lr[ld].dw, 3, 2)
                 g = ops.conv_dgrad(dyd, Lr[ld].pk, hw[0], out=self._scratch(A, "g0", x_prev.shape))
             else:
-                ops.conv_wgrad(x_prev, dyd, Lr[ld].dw, 3, 2)
+                self._wgrad(x_prev, dyd, Lr[ld].dw, 3, 2)
                 add = None
                 if st == 4:
                     add = d_skip[0]      # f2 (stage-4 output) also fed the scale-2 concat
@@ -423,11 +439,21 @@ class Network:
                 on_layer_done(ld)
             i -= 1
         dy0 = self._bwd_bn(A, 0, g)
-        self._stem_dw.zero_()
-        ops.conv_wgrad(A["im2col"], dy0, self._stem_dw, 1, 1)
-        Lr[0].dw.view(32, 27).add_(self._stem_dw.view(32, 32)[:, :27])
+        ev = torch.cuda.Event()
+        ev.record()
+        side = self.wg_stream if self.overlap_wgrad else torch.cuda.current_stream()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            self._stem_dw.zero_()
+            ops.conv_wgrad(A["im2col"], dy0, self._stem_dw, 1, 1)
+            Lr[0].dw.view(32, 27).add_(self._stem_dw.view(32, 32)[:, :27])
+        self._join_wgrad()
         if on_layer_done:
             on_layer_done(0)
+
+    def _join_wgrad(self):
+        if self.overlap_wgrad:
+            torch.cuda.current_stream().wait_stream(self.wg_stream)
 
     def _wire(self, A):
         """Forward input activation of each backbone conv, per arena."""

@@ -36,7 +36,8 @@ class TrainStep:
         self._loss = {}
         self._douts = {}
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
-        self.dp = GradBuckets(net.grads, [cv.off_w for cv in net.layers], world_size, bucket_mb, self.comm_stream)
+        self.dp = GradBuckets(net.grads, [cv.off_w for cv in net.layers], world_size, bucket_mb, self.comm_stream,
+                              producer_streams=(net.wg_stream,))
 
     # ------------------------------------------------------------------ helpers
     def _grids(self, H, W):
