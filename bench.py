@@ -178,6 +178,8 @@ def main():
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": None, "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                 "event_steps": 1, "share_of_step_time": round(ms / (dt * 1e3 / args.steps), 3),
+                "note": "durations include CU sharing with conv_wgrad2_kernel, which runs concurrently on a side stream",
+                "whole_step_conv_tflops": round(ips / world * 3 * FLOP_PER_IMAGE_FWD * (args.size / 608) ** 2 / 1e12, 1),
                 "algorithmic_flop_per_launch_avg": round(fl / max(n, 1) / 1e9, 2)}
     out = {
         "metric": "images/sec (train step, 608x608, bs/GPU=16)", "value": round(ips, 2), "unit": "images/sec",

@@ -64,6 +64,17 @@ typedef struct mgd_conv_desc {
   int32_t K_pad, Co_pad; /* of wpk                                                */
   int32_t dst_f32;
   int32_t stats_replicas;
+  /* Optional: when dst is the activation gradient `da` of a BatchNorm+LeakyReLU layer, fold that layer's
+   * backward reduction into this launch: bn_sums[(block % stats_replicas)][2][Co] += { sum dyh, sum dyh*yhat }
+   * over the tile, dyh = da * leaky'(bn_y*bn_scale+bn_shift), yhat = (bn_y - bn_mean)*bn_invstd (what
+   * mgd_bn_act_bwd_reduce computes in a separate pass).  bn_y has dst's shape. */
+  const void* bn_y;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_invstd;
+  float* bn_sums;
+  float bn_slope;
 } mgd_conv_desc;
 
 int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream);

@@ -37,6 +37,11 @@ struct GemmArgs {
   int nblk;
   int dbg;      // diagnostic only (MGD_DBG): 1 = all LDS-DMA loads hit one cache line, 2 = phase stamps
   unsigned long long* stamps;
+  // fused BN-backward reduction of the CONSUMER layer over the tile just produced (dst = da of that layer)
+  const bf16_t* bn_y;
+  const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
+  float* bn_sums;
+  float bn_slope;
 };
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * ROWB + ((kc ^ (row & 7)) << 4); }
@@ -524,6 +529,21 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
     }
   }
   const int CPR = BNC * esz / 16;
+  // optional fused reduction for the BatchNorm backward of the layer that consumes this tensor as its da:
+  // sums += { sum dyh, sum dyh * yhat } per channel, dyh = da * leaky'(y*scale+shift)   (NTHR % CPR == 0, so a
+  // thread always owns the same 8 channels)
+  const bool bnred = a.bn_y != nullptr && !a.dst_f32;
+  float bsc[8], bsh[8], bmu[8], biv[8], r1[8], r2[8];
+  if (bnred) {
+    int c = co0 + (tid % CPR) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bool ok = c + j < a.Co;
+      bsc[j] = ok ? a.bn_scale[c + j] : 0.f; bsh[j] = ok ? a.bn_shift[c + j] : 0.f;
+      bmu[j] = ok ? a.bn_mean[c + j] : 0.f;  biv[j] = ok ? a.bn_invstd[c + j] : 0.f;
+      r1[j] = r2[j] = 0.f;
+    }
+  }
   for (int q = tid; q < BMP * CPR; q += NTHR) {
     int r = q / CPR, ch = q - r * CPR;
     long long off = row_dst[r];
@@ -543,6 +563,40 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
         v = pack8(f);
       }
       *(uint4*)((bf16_t*)a.dst + off + c) = v;
+      if (bnred) {
+        float d[8], yv[8];
+        unpack8(v, d);
+        unpack8(*(const uint4*)(a.bn_y + off + c), yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float z = fmaf(yv[j], bsc[j], bsh[j]);
+          float dd = z > 0.f ? d[j] : d[j] * a.bn_slope;
+          r1[j] += dd;
+          r2[j] += dd * (yv[j] - bmu[j]) * biv[j];
+        }
+      }
+    }
+  }
+  if (bnred) {
+    __syncthreads();
+    if (tid < 2 * BNC) colred[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x1 = r1[j], x2 = r2[j];
+      for (int o = CPR; o < 64; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
+      if (lane < CPR) {
+        atomicAdd(&colred[lane * 8 + j], x1);
+        atomicAdd(&colred[BNC + lane * 8 + j], x2);
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BNC) {
+      int which = tid / BNC, col = tid - which * BNC;
+      if (co0 + col < a.Co) {
+        int rep = blockIdx.x % a.stats_replicas;
+        atomicAdd(a.bn_sums + ((long long)rep * 2 + which) * a.Co + co0 + col, colred[tid]);
+      }
     }
   }
 }
@@ -1468,6 +1522,11 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   if (dbg < 0) { const char* e = getenv("MGD_DBG"); dbg = e ? atoi(e) : 0; }
   a.dbg = dbg;
   a.stamps = nullptr;
+  a.bn_y = (const bf16_t*)d->bn_y; a.bn_scale = d->bn_scale; a.bn_shift = d->bn_shift; a.bn_mean = d->bn_mean;
+  a.bn_invstd = d->bn_invstd; a.bn_sums = d->bn_sums; a.bn_slope = d->bn_slope;
+  MGD_REQUIRE(!d->bn_y || (d->bn_scale && d->bn_shift && d->bn_mean && d->bn_invstd && d->bn_sums && d->stats_replicas >= 1),
+              "conv: fused BN-backward reduction needs scale/shift/mean/invstd/sums and stats_replicas");
+
   hipStream_t st = (hipStream_t)stream;
   static int variant = -1;
   if (variant < 0) {
@@ -1475,6 +1534,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     variant = e ? atoi(e) : 3;
   }
   const int nk = d->K_pad / BK;
+  MGD_REQUIRE(!d->bn_y || variant == 3, "conv: the fused BN-backward reduction needs the default gemm variant (MGD_GEMM=3)");
   if (variant == 1) {
     if (d->Co_pad % 128 == 0) launch_gemm<2, 2, 4, 4>(a, st);
     else if (d->Co_pad % 64 == 0) launch_gemm<1, 4, 4, 2>(a, st);

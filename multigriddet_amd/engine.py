@@ -125,6 +125,7 @@ class Network:
         # leave idle.  Needs one dy buffer per layer (no scratch reuse while a side-stream wgrad may read it).
         self.overlap_wgrad = True
         self.wg_stream = torch.cuda.Stream(device=dev)
+        self.fuse_bn_reduce = False     # BN-backward reduction inside the dgrad epilogue that produces `da` (A/B: 0.35 ms slower per step than the overlapped stand-alone reduce, so opt-in)
         self._arenas = {}
         self.reset_parameters(seed)
 
@@ -310,13 +311,23 @@ class Network:
         return outs
 
     # ------------------------------------------------------------------ backward
+    def _bnred(self, A, i):
+        """BN context of layer i for a dgrad launch that writes layer i's `da`: the backward reduction
+        (sum dyh, sum dyh*yhat) is then fused into that launch's epilogue.  None if the layer's BN is frozen."""
+        cv = self.layers[i]
+        if not self.fuse_bn_reduce or not self._bn_training(cv):
+            return None
+        A["reduced"].add(i)
+        return (A["y"][i], cv.scale, cv.shift, cv.smean, cv.sinv, cv.sums)
+
     def _bwd_bn(self, A, i, da):
         """da: grad wrt the activated output of layer i -> returns dy (grad wrt the raw conv output)."""
         cv = self.layers[i]
         y = A["y"][i]
         dy = self._scratch(A, ("dy", i) if self.overlap_wgrad else "dy", y.shape)
         frozen = not self._bn_training(cv)
-        ops.bn_act_bwd(da, y, cv.scale, cv.shift, cv.smean, cv.sinv, cv.sums, cv.dgamma, cv.dbeta, dy, frozen=frozen)
+        ops.bn_act_bwd(da, y, cv.scale, cv.shift, cv.smean, cv.sinv, cv.sums, cv.dgamma, cv.dbeta, dy, frozen=frozen,
+                       reduced=i in A["reduced"])
         return dy
 
     def _wgrad(self, x, dy, dw, k, s):
@@ -343,6 +354,7 @@ class Network:
         if "fin" not in A:
             self._wire(A)
         fin = A["fin"]
+        A["reduced"] = set()
 
         def inp(i):
             return fin[i]
@@ -363,24 +375,27 @@ class Network:
                 on_layer_done(c5)
             if pred_only:
                 continue
-            d_a4 = ops.conv_dgrad(dy5, pred.pk, hw[c4], out=self._scratch(A, "da_a", a4.shape))
+            d_a4 = ops.conv_dgrad(dy5, pred.pk, hw[c4], out=self._scratch(A, "da_a", a4.shape), bnred=self._bnred(A, c4))
             dy4 = self._bwd_bn(A, c4, d_a4)
             xb = acts[c3]
             self._wgrad(xb, dy4, Lr[c4].dw, 3, 1)
-            d_xb = ops.conv_dgrad(dy4, Lr[c4].pk, hw[c3], out=self._scratch(A, "da_b", xb.shape))
+            # xb (= activation of c3) has a second consumer (the lateral conv c6) unless this is the last scale:
+            # the launch that writes the FINAL d_xb carries c3's BN reduction
+            d_xb = ops.conv_dgrad(dy4, Lr[c4].pk, hw[c3], out=self._scratch(A, "da_b", xb.shape),
+                                  bnred=self._bnred(A, c3) if sc == 2 else None)
             if sc < 2:
                 c6 = base + 5
                 dy6 = self._bwd_bn(A, c6, d_up[sc])
                 self._wgrad(xb, dy6, Lr[c6].dw, 1, 1)
-                ops.conv_dgrad(dy6, Lr[c6].pk, hw[c3], out=d_xb, addend=d_xb)
+                ops.conv_dgrad(dy6, Lr[c6].pk, hw[c3], out=d_xb, addend=d_xb, bnred=self._bnred(A, c3))
             dy3 = self._bwd_bn(A, c3, d_xb)
             a2 = acts[c2]
             self._wgrad(a2, dy3, Lr[c3].dw, 1, 1)
-            d_a2 = ops.conv_dgrad(dy3, Lr[c3].pk, hw[c2], out=self._scratch(A, "da_a", a2.shape))
+            d_a2 = ops.conv_dgrad(dy3, Lr[c3].pk, hw[c2], out=self._scratch(A, "da_a", a2.shape), bnred=self._bnred(A, c2))
             dy2 = self._bwd_bn(A, c2, d_a2)
             a1 = acts[c1]
             self._wgrad(a1, dy2, Lr[c2].dw, 3, 1)
-            d_a1 = ops.conv_dgrad(dy2, Lr[c2].pk, hw[c1], out=self._scratch(A, "da_b", a1.shape))
+            d_a1 = ops.conv_dgrad(dy2, Lr[c2].pk, hw[c1], out=self._scratch(A, "da_b", a1.shape), bnred=self._bnred(A, c1))
             dy1 = self._bwd_bn(A, c1, d_a1)
             xin = A["cat"][sc - 1] if sc > 0 else acts[BACKBONE_CONVS - 1]
             self._wgrad(xin, dy1, Lr[c1].dw, 1, 1)
@@ -397,7 +412,8 @@ class Network:
                 d_skip[sc - 1] = dsk
                 d_up[sc - 1] = du
             elif not train_head_only:
-                g_f1 = ops.conv_dgrad(dy1, Lr[c1].pk, hw[c1], out=self._scratch(A, "g5", acts[BACKBONE_CONVS - 1].shape))
+                g_f1 = ops.conv_dgrad(dy1, Lr[c1].pk, hw[c1], out=self._scratch(A, "g5", acts[BACKBONE_CONVS - 1].shape),
+                                      bnred=self._bnred(A, BACKBONE_CONVS - 1))
         if pred_only or train_head_only:
             self._join_wgrad()
             if on_layer_done:
@@ -414,10 +430,12 @@ class Network:
                 dy2 = self._bwd_bn(A, l2, g)                     # residual branch: d a2 = g
                 a1 = acts[l1]
                 self._wgrad(a1, dy2, Lr[l2].dw, 3, 1)
-                d_a1 = ops.conv_dgrad(dy2, Lr[l2].pk, hw[l1], out=self._scratch(A, "da_a", a1.shape))
+                d_a1 = ops.conv_dgrad(dy2, Lr[l2].pk, hw[l1], out=self._scratch(A, "da_a", a1.shape),
+                                      bnred=self._bnred(A, l1))
                 dy1 = self._bwd_bn(A, l1, d_a1)
                 self._wgrad(x_in, dy1, Lr[l1].dw, 1, 1)
-                ops.conv_dgrad(dy1, Lr[l1].pk, hw[l1], out=g, addend=g)      # g <- g + dgrad (in place)
+                # g <- g + dgrad (in place); g is then the `da` of the layer that produced x_in (l1 - 1)
+                ops.conv_dgrad(dy1, Lr[l1].pk, hw[l1], out=g, addend=g, bnred=self._bnred(A, l1 - 1))
                 if on_layer_done:
                     on_layer_done(l1)
                 i -= 2
@@ -426,7 +444,7 @@ class Network:
             dyd = self._bwd_bn(A, ld, g)
             if st == 0:
                 self._wgrad(x_prev, dyd, Lr[ld].dw, 3, 2)
-                g = ops.conv_dgrad(dyd, Lr[ld].pk, hw[0], out=self._scratch(A, "g0", x_prev.shape))
+                g = ops.conv_dgrad(dyd, Lr[ld].pk, hw[0], out=self._scratch(A, "g0", x_prev.shape), bnred=self._bnred(A, 0))
             else:
                 self._wgrad(x_prev, dyd, Lr[ld].dw, 3, 2)
                 add = None
@@ -434,7 +452,8 @@ class Network:
                     add = d_skip[0]      # f2 (stage-4 output) also fed the scale-2 concat
                 elif st == 3:
                     add = d_skip[1]      # f3 (stage-3 output) also fed the scale-3 concat
-                g = ops.conv_dgrad(dyd, Lr[ld].pk, hw[ld - 1], out=self._scratch(A, f"g{st}", x_prev.shape), addend=add)
+                g = ops.conv_dgrad(dyd, Lr[ld].pk, hw[ld - 1], out=self._scratch(A, f"g{st}", x_prev.shape), addend=add,
+                                   bnred=self._bnred(A, ld - 1))
             if on_layer_done:
                 on_layer_done(ld)
             i -= 1

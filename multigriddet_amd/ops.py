@@ -140,7 +140,7 @@ def stem_im2col(image, out=None):
 
 
 def _desc(src, wpk, dst, N, Hs, Ws, Ci, Hg, Wg, Hd, Wd, Co, in_stride, out_stride, off, dh, dw, K_pad, Co_pad,
-          bias=None, addend=None, stats=None, dst_f32=False):
+          bias=None, addend=None, stats=None, dst_f32=False, bnred=None):
     d = L.ConvDesc()
     d.src, d.wpk, d.dst = src.data_ptr(), wpk.data_ptr(), dst.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -152,7 +152,12 @@ def _desc(src, wpk, dst, N, Hs, Ws, Ci, Hg, Wg, Hd, Wd, Co, in_stride, out_strid
     for i, (a, b) in enumerate(zip(dh, dw)):
         d.dh[i], d.dw[i] = a, b
     d.K_pad, d.Co_pad, d.dst_f32 = K_pad, Co_pad, int(dst_f32)
-    d.stats_replicas = STATS_REPLICAS if stats is not None else 0
+    d.stats_replicas = STATS_REPLICAS if (stats is not None or bnred is not None) else 0
+    if bnred is not None:       # (y, scale, shift, mean, invstd, sums) of the layer whose `da` this launch writes
+        y, sc, sh, mu, iv, sums = bnred
+        d.bn_y, d.bn_scale, d.bn_shift = y.data_ptr(), sc.data_ptr(), sh.data_ptr()
+        d.bn_mean, d.bn_invstd, d.bn_sums = mu.data_ptr(), iv.data_ptr(), sums.data_ptr()
+        d.bn_slope = LEAKY_SLOPE
     return d
 
 
@@ -170,8 +175,9 @@ def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False):
     return out
 
 
-def conv_dgrad(dy, pk, in_hw, out=None, addend=None):
-    """dy: bf16 [N,Ho,Wo,Co] -> dx bf16 [N,H,W,Ci] (+ addend)."""
+def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
+    """dy: bf16 [N,Ho,Wo,Co] -> dx bf16 [N,H,W,Ci] (+ addend).  bnred = (y, scale, shift, mean, invstd, sums) of
+    the BatchNorm layer that produced the forward input: its backward reduction is fused into the epilogue."""
     N, Ho, Wo, Co = dy.shape
     H, W = in_hw
     assert Co == pk.co and dy.dtype == torch.bfloat16
@@ -181,12 +187,13 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None):
     if pk.s == 1:
         img, kp, cp, _, _ = pk.dgrad[0]
         dh, dw = taps_fwd(pk.k)
-        d = _desc(dy, img, out, N, Ho, Wo, Co, H, W, H, W, pk.ci, 1, 1, (0, 0), dh, dw, kp, cp, addend=addend)
+        d = _desc(dy, img, out, N, Ho, Wo, Co, H, W, H, W, pk.ci, 1, 1, (0, 0), dh, dw, kp, cp, addend=addend,
+                  bnred=bnred)
         _launch_gemm(d, "conv_dgrad")
     else:
         for img, kp, cp, _, (ph, pw, tp) in pk.dgrad:
             d = _desc(dy, img, out, N, Ho, Wo, Co, H // 2, W // 2, H, W, pk.ci, 1, 2, (ph, pw),
-                      [t[0] for t in tp], [t[1] for t in tp], kp, cp, addend=addend)
+                      [t[0] for t in tp], [t[1] for t in tp], kp, cp, addend=addend, bnred=bnred)
             _launch_gemm(d, "conv_dgrad_s2")
     return out
 
@@ -267,12 +274,13 @@ def bn_act_fwd_fused(stats, count, gamma, beta, mm, mv, scale, shift, smean, sin
     return out
 
 
-def bn_act_bwd(da, y, scale, shift, smean, sinv, sums, dgamma, dbeta, dy, frozen=False):
-    """sums: fp32 [(R+1)*2*C] zeroed scratch.  Writes dy, accumulates dgamma/dbeta."""
+def bn_act_bwd(da, y, scale, shift, smean, sinv, sums, dgamma, dbeta, dy, frozen=False, reduced=False):
+    """sums: fp32 [(R+1)*2*C] zeroed scratch.  Writes dy, accumulates dgamma/dbeta.  reduced=True: the sums were
+    already accumulated by the producer of `da` (conv_dgrad(..., bnred=...))."""
     Cn = y.shape[-1]
     P = y.numel() // Cn
     lib = L.load()
-    if not frozen:
+    if not frozen and not reduced:
         L.check(lib.mgd_bn_act_bwd_reduce(L.ptr(da), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(smean),
                                           L.ptr(sinv), L.ptr(sums), STATS_REPLICAS, C.c_int64(P), Cn,
                                           C.c_float(LEAKY_SLOPE), L.stream_ptr()), "bn_act_bwd_reduce")

@@ -201,6 +201,34 @@ def test_bn_act_fwd_bwd(dev, C, P, res):
     assert e <= 0.02 * yr.grad.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("N,H,W,Ci,Co,k,s", [(2, 20, 20, 64, 128, 3, 1), (2, 24, 24, 32, 64, 3, 2), (3, 19, 19, 256, 128, 1, 1)])
+def test_dgrad_fused_bn_reduction(dev, N, H, W, Ci, Co, k, s):
+    """conv_dgrad(..., bnred=...) must leave in `sums` exactly what mgd_bn_act_bwd_reduce computes from its output."""
+    from multigriddet_amd import ops
+    import ctypes as Ct
+    L = ops.L
+    g = torch.Generator().manual_seed(77 + Ci)
+    pk = ops.PackedConv(Co, Ci, k, s, dev)
+    pk.refresh((torch.randn(Co, k * k, Ci, generator=g) / (k * Ci ** 0.5)).to(dev))
+    Ho, Wo = H // s, W // s
+    dy = bf(torch.randn(N, Ho, Wo, Co, generator=g)).to(dev)
+    yprev = bf(torch.randn(N, H, W, Ci, generator=g) + 0.2).to(dev)          # raw conv output of the producer layer
+    add = bf(torch.randn(N, H, W, Ci, generator=g)).to(dev)
+    sc, sh = (torch.rand(Ci, generator=g) + 0.5).to(dev), (torch.randn(Ci, generator=g) * 0.3).to(dev)
+    mu, iv = (torch.randn(Ci, generator=g) * 0.2).to(dev), (torch.rand(Ci, generator=g) + 0.5).to(dev)
+    R = ops.STATS_REPLICAS
+    sums_f = torch.zeros((R + 1) * 2 * Ci, device=dev)
+    dx = ops.conv_dgrad(dy, pk, (H, W), addend=add, bnred=(yprev, sc, sh, mu, iv, sums_f))
+    sums_r = torch.zeros((R + 1) * 2 * Ci, device=dev)
+    P = N * H * W
+    L.check(L.load().mgd_bn_act_bwd_reduce(L.ptr(dx), L.ptr(yprev), L.ptr(sc), L.ptr(sh), L.ptr(mu), L.ptr(iv),
+                                           L.ptr(sums_r), R, Ct.c_int64(P), Ci, Ct.c_float(0.1), L.stream_ptr()))
+    torch.cuda.synchronize()
+    a = sums_f[:R * 2 * Ci].view(R, 2, Ci).sum(0).cpu().numpy()
+    b = sums_r[:R * 2 * Ci].view(R, 2, Ci).sum(0).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-3 * np.abs(b).max())
+
+
 def test_pack_batch_matches_single_packs(dev):
     from multigriddet_amd import ops
     g = torch.Generator().manual_seed(2)
