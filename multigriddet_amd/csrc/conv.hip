@@ -327,6 +327,42 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
     row_dst[tid] = off;
   }
 
+  // bf16 epilogue operands that live in HBM (residual-gradient addend, y of the fused BN-backward reduction) are
+  // fetched here, before the K-loop, so their latency hides under the main loop instead of being paid eight times
+  // in a row by the epilogue.  (Fetching them from inside the K-loop, a few steps before its end, was tried: the
+  // extra branch cost the loop its schedule and every layer 30-60 %.)
+  constexpr int CPB = BNC / 8;                 // 16-byte bf16 chunks per output row
+  constexpr int EPC = BMP * CPB / NTHR;        // chunks per thread
+  static_assert(BMP * CPB % NTHR == 0 && NTHR % CPB == 0, "epilogue mapping");
+  const bool bnred = a.bn_y != nullptr && !a.dst_f32;
+  const bool addpre = a.addend != nullptr && !a.dst_f32;
+  float bnp[4][8];                             // scale, shift, mean, invstd of my 8 channels (bnred only)
+  if (bnred) {
+    const int c = co0 + (tid % CPB) * 8;
+    const float* ps[4] = {a.bn_scale, a.bn_shift, a.bn_mean, a.bn_invstd};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+      if (c < a.Co) { lo = *(const f32x4*)(ps[k] + c); hi = *(const f32x4*)(ps[k] + c + 4); }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bnp[k][j] = lo[j]; bnp[k][4 + j] = hi[j]; }
+    }
+  }
+  uint4 ypre[EPC], apre[EPC];
+  if (bnred || addpre) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < EPC; ++it) {
+      const int q = tid + it * NTHR;
+      const int r = q / CPB, ch = q - r * CPB;
+      const long long off = row_dst[r];
+      const int c = co0 + ch * 8;
+      const bool ok = off >= 0 && c < a.Co;
+      ypre[it] = (bnred && ok) ? *(const uint4*)(a.bn_y + off + c) : make_uint4(0, 0, 0, 0);
+      apre[it] = (addpre && ok) ? *(const uint4*)(a.addend + off + c) : make_uint4(0, 0, 0, 0);
+    }
+  }
+
   // thread -> LDS slot (tid & 7) of rows (tid >> 3) + RPR i ; source chunk kc = slot ^ (row & 7).
   // Address generation is kept off the critical path (the first version spent 5.7 VALU instructions
   // per MFMA on it): per row a 32-bit byte offset and a 9-bit tap-validity mask are computed once; per
@@ -502,100 +538,89 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
     }
   }
   __syncthreads();
-  const int rows_valid = min(BMP, a.M - pix0);
-  if (a.stats && !a.dst_f32) {
-    constexpr int NCP = BNC / 2, RG = NTHR / NCP, RPG = BMP / RG;
-    if (tid < 2 * BNC) colred[tid] = 0.f;
-    __syncthreads();
-    int cp = tid % NCP, rg = tid / NCP;
-    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-    int rend = min(rows_valid, (rg + 1) * RPG);
-    for (int r = rg * RPG; r < rend; ++r) {
-      uint32_t u = *(const uint32_t*)(smem + r * EROW + cp * 4);
-      float v0 = __uint_as_float(u << 16), v1 = __uint_as_float(u & 0xffff0000u);
-      s0 += v0; s1 += v1; q0 += v0 * v0; q1 += v1 * v1;
-    }
-    atomicAdd(&colred[2 * cp], s0);
-    atomicAdd(&colred[2 * cp + 1], s1);
-    atomicAdd(&colred[BNC + 2 * cp], q0);
-    atomicAdd(&colred[BNC + 2 * cp + 1], q1);
-    __syncthreads();
-    if (tid < 2 * BNC) {
-      int which = tid / BNC, col = tid - which * BNC;
-      if (co0 + col < a.Co) {
-        int rep = blockIdx.x % a.stats_replicas;
-        atomicAdd(a.stats + ((long long)rep * 2 + which) * a.Co + co0 + col, colred[tid]);
-      }
-    }
-  }
   const int CPR = BNC * esz / 16;
-  // optional fused reduction for the BatchNorm backward of the layer that consumes this tensor as its da:
-  // sums += { sum dyh, sum dyh * yhat } per channel, dyh = da * leaky'(y*scale+shift)   (NTHR % CPR == 0, so a
-  // thread always owns the same 8 channels)
-  const bool bnred = a.bn_y != nullptr && !a.dst_f32;
-  float bsc[8], bsh[8], bmu[8], biv[8], r1[8], r2[8];
-  if (bnred) {
-    int c = co0 + (tid % CPR) * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      bool ok = c + j < a.Co;
-      bsc[j] = ok ? a.bn_scale[c + j] : 0.f; bsh[j] = ok ? a.bn_shift[c + j] : 0.f;
-      bmu[j] = ok ? a.bn_mean[c + j] : 0.f;  biv[j] = ok ? a.bn_invstd[c + j] : 0.f;
-      r1[j] = r2[j] = 0.f;
+  if (a.dst_f32) {
+    for (int q = tid; q < BMP * CPR; q += NTHR) {
+      int r = q / CPR, ch = q - r * CPR;
+      long long off = row_dst[r];
+      int c = co0 + ch * 4;
+      if (off < 0 || c >= a.Co) continue;
+      *(uint4*)((float*)a.dst + off + c) = *(const uint4*)(smem + r * EROW + ch * 16);
     }
+    return;
   }
-  for (int q = tid; q < BMP * CPR; q += NTHR) {
-    int r = q / CPR, ch = q - r * CPR;
-    long long off = row_dst[r];
-    int c = co0 + ch * (16 / esz);
+  // bf16 rows.  NTHR % CPB == 0, so a thread owns the same 8 channels in every row it writes, and both per-channel
+  // reductions ride on the output loop in registers:
+  //   stats  (forward, BatchNorm batch statistics):  r1 = sum y, r2 = sum y^2 of the bf16-ROUNDED values;
+  //   bnred  (data gradient; BatchNorm backward of the layer that consumes this tensor as its da):
+  //          r1 = sum dyh, r2 = sum dyh * yhat,  dyh = da * leaky'(y*scale+shift).
+  // The residual-gradient addend and y were fetched before the K-loop (apre / ypre).
+  const bool stats = a.stats != nullptr;
+  float r1[8], r2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r1[j] = r2[j] = 0.f;
+#pragma unroll
+  for (int it = 0; it < EPC; ++it) {
+    const int q = tid + it * NTHR;
+    const int r = q / CPB, ch = q - r * CPB;
+    const long long off = row_dst[r];
+    const int c = co0 + ch * 8;
     if (off < 0 || c >= a.Co) continue;
     uint4 v = *(const uint4*)(smem + r * EROW + ch * 16);
-    if (a.dst_f32) {
-      *(uint4*)((float*)a.dst + off + c) = v;
-    } else {
-      if (a.addend) {
-        uint4 ad = *(const uint4*)(a.addend + off + c);
-        float f[8], g[8];
-        unpack8(v, f);
-        unpack8(ad, g);
+    if (addpre) {
+      float f[8], g[8];
+      unpack8(v, f);
+      unpack8(apre[it], g);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] += g[j];
-        v = pack8(f);
-      }
-      *(uint4*)((bf16_t*)a.dst + off + c) = v;
-      if (bnred) {
-        float d[8], yv[8];
-        unpack8(v, d);
-        unpack8(*(const uint4*)(a.bn_y + off + c), yv);
+      for (int j = 0; j < 8; ++j) f[j] += g[j];
+      v = pack8(f);
+    }
+    *(uint4*)((bf16_t*)a.dst + off + c) = v;
+    if (stats) {
+      float d[8];
+      unpack8(v, d);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float z = fmaf(yv[j], bsc[j], bsh[j]);
-          float dd = z > 0.f ? d[j] : d[j] * a.bn_slope;
-          r1[j] += dd;
-          r2[j] += dd * (yv[j] - bmu[j]) * biv[j];
-        }
+      for (int j = 0; j < 8; ++j) { r1[j] += d[j]; r2[j] = fmaf(d[j], d[j], r2[j]); }
+    } else if (bnred) {
+      float d[8], yv[8];
+      unpack8(v, d);
+      unpack8(ypre[it], yv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float z = fmaf(yv[j], bnp[0][j], bnp[1][j]);
+        float dd = z > 0.f ? d[j] : d[j] * a.bn_slope;
+        r1[j] += dd;
+        r2[j] = fmaf(dd * (yv[j] - bnp[2][j]), bnp[3][j], r2[j]);
       }
     }
   }
-  if (bnred) {
-    __syncthreads();
-    if (tid < 2 * BNC) colred[tid] = 0.f;
-    __syncthreads();
+  if (stats || bnred) {
+    // lanes with equal (lane % CPB) own the same channels: butterfly over the other lane bits, one partial row per
+    // wave in LDS (above the bf16 tile, inside the fp32-sized epilogue region), then 2*BNC threads fold the waves
+    // and issue one global atomic each into replica (block % R).
+    float* wred = (float*)(smem + BMP * (BNC * 2 + 16));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float x1 = r1[j], x2 = r2[j];
-      for (int o = CPR; o < 64; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
-      if (lane < CPR) {
-        atomicAdd(&colred[lane * 8 + j], x1);
-        atomicAdd(&colred[BNC + lane * 8 + j], x2);
+#pragma unroll
+      for (int o = CPB; o < 64; o <<= 1) { r1[j] += __shfl_xor(r1[j], o, 64); r2[j] += __shfl_xor(r2[j], o, 64); }
+    }
+    if (lane < CPB) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        wred[wave * 2 * BNC + lane * 8 + j] = r1[j];
+        wred[wave * 2 * BNC + BNC + lane * 8 + j] = r2[j];
       }
     }
     __syncthreads();
     if (tid < 2 * BNC) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NTHR / 64; ++w) t += wred[w * 2 * BNC + tid];
       int which = tid / BNC, col = tid - which * BNC;
       if (co0 + col < a.Co) {
         int rep = blockIdx.x % a.stats_replicas;
-        atomicAdd(a.bn_sums + ((long long)rep * 2 + which) * a.Co + co0 + col, colred[tid]);
+        float* dstp = stats ? a.stats : a.bn_sums;
+        atomicAdd(dstp + ((long long)rep * 2 + which) * a.Co + co0 + col, t);
       }
     }
   }
