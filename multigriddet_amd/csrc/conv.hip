@@ -1065,6 +1065,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+// ds_read_b64_tr_b16 the compiler does not see (no automatic waits: pair with wait_lgkm_dyn + touch)
+template <int OFF>
+__device__ __forceinline__ void tr_read_asm(s16x4& dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// orders the consumers of v after the preceding wait (the asm "modifies" v)
+__device__ __forceinline__ void touch(s16x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void wait_lgkm_dyn(int n) {   // n is a compile-time constant after unrolling
+  switch (n) {
+    case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Weight gradient v2: same MFMA/tr-read structure, operands staged by LDS-DMA into a 2-deep ring
 // (one raw barrier per 64-pixel K-step, the next stage's loads in flight during the MFMAs).
@@ -1145,39 +1174,64 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 
   if (nk > 0) issue(0, 0);
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  // fragment read offsets inside a stage: MFMA k index = pixel row kk*32 + 8g + qq (+4 for the upper half)
+  int o_rd[2][2][MT], i_rd[2][2][NT];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r0 = kk * 32 + 8 * g + qq + 4 * h;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) o_rd[kk][h][m] = r0 * RBO + (((wc * MT + m) ^ tr_swz(r0, RBO / 32)) * 32) + pp * 8;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        i_rd[kk][h][n] = 64 * RBO + r0 * RBI + (((wi * NT + n) ^ tr_swz(r0, RBI / 32)) * 32) + pp * 8;
+    }
+  // The transposed fragment reads go out from inline asm: in front of a ds_read_b64_tr_b16 it can see, the compiler
+  // puts s_waitcnt vmcnt(0) (it cannot tell the read from the LDS-DMA writes in flight), which made every K-step
+  // wait for the NEXT stage's loads before computing the current one.  Waits are explicit instead.
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const unsigned smem_a = lds_addr(smem);
   for (int ks = 0; ks < nk; ++ks) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
-    const unsigned char* ob = smem + (ks & 1) * STAGE;
-    const unsigned char* ib = ob + 64 * RBO;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int r0 = kk * 32 + 8 * g + qq;
-      bf16x8 of[MT], xf[NT];
-      typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const unsigned sb = smem_a + (ks & 1) * STAGE;
+    s16x4 fa[2][MT][2], fb[2][NT][2];
+    auto read_half = [&](int kk) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        int c32 = wc * MT + m;
-        s16x4 lo = ds_read_tr16(ob + r0 * RBO + ((c32 ^ tr_swz(r0, RBO / 32)) * 32) + pp * 8);
-        s16x4 hi = ds_read_tr16(ob + (r0 + 4) * RBO + ((c32 ^ tr_swz(r0 + 4, RBO / 32)) * 32) + pp * 8);
-        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        of[m] = __builtin_bit_cast(bf16x8, v);
+        tr_read_asm<0>(fa[kk][m][0], sb + o_rd[kk][0][m]);
+        tr_read_asm<0>(fa[kk][m][1], sb + o_rd[kk][1][m]);
       }
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        int c32 = wi * NT + n;
-        s16x4 lo = ds_read_tr16(ib + r0 * RBI + ((c32 ^ tr_swz(r0, RBI / 32)) * 32) + pp * 8);
-        s16x4 hi = ds_read_tr16(ib + (r0 + 4) * RBI + ((c32 ^ tr_swz(r0 + 4, RBI / 32)) * 32) + pp * 8);
-        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        xf[n] = __builtin_bit_cast(bf16x8, v);
+        tr_read_asm<0>(fb[kk][n][0], sb + i_rd[kk][0][n]);
+        tr_read_asm<0>(fb[kk][n][1], sb + i_rd[kk][1][n]);
       }
+    };
+    auto mfma_half = [&](int kk) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m) { touch(fa[kk][m][0]); touch(fa[kk][m][1]); }
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of[m], xf[n], acc[m][n], 0, 0, 0);
-    }
+      for (int n = 0; n < NT; ++n) { touch(fb[kk][n][0]); touch(fb[kk][n][1]); }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        s16x8 av = __builtin_shufflevector(fa[kk][m][0], fa[kk][m][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          s16x8 bv = __builtin_shufflevector(fb[kk][n][0], fb[kk][n][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                             acc[m][n], 0, 0, 0);
+        }
+      }
+    };
+    read_half(0);
+    wait_lgkm_dyn(0);
+    read_half(1);          // in flight under the MFMAs of the first half
+    mfma_half(0);
+    wait_lgkm_dyn(0);
+    mfma_half(1);
   }
   __syncthreads();
 
@@ -1201,6 +1255,241 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
       atomicAdd(a.dw + ((long long)co * a.ntaps + tap) * a.Ci + ci, v);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient v3 ("patch" form) for 3x3 convs with few input channels (Ci = 32 or 64), stride 1 or 2.
+// With so few channels the per-tap blocks of v2 move 3x more LDS-DMA bytes per FLOP than a 128x128 tile and
+// re-read dy nine times.  Here one block owns ALL nine taps of a [64 co] x [Ci] slice: per K-step (an
+// R x TW = 4 x 16 patch of output pixels of one image) it stages the dy tile and ONE haloed input patch
+// ((R-1)s+3) x ((TW-1)s+3) pixels; the nine taps read the same patch at shifted addresses.  Patch pixels
+// are stored at a padded pitch (Ci*2 + 32 bytes) so that the transposed fragment reads of any tap spread
+// over the LDS banks without a per-address swizzle; out-of-image pixels and the pad lanes are DMA'd from a
+// zero page.  9 x MT x NT accumulators per wave; the epilogue adds them to dW with 64-byte-contiguous fp32
+// atomics straight from registers (the memory-side atomic unit works on 64-byte requests anyway).
+struct Wgrad3Args {
+  const bf16_t* src;
+  const bf16_t* dy;
+  float* dw;
+  int N, Hs, Ws, Ci, Hg, Wg, Co;
+  int s, R, TW, PC, PP;     // stride, output tile, patch columns, patch pixels
+  int tilesH, tilesW, ntiles, per_split, tilesCo;
+  int nst;                  // ring stages (2..6), one block per CU
+  int dbg;                  // diagnostics: 16 = no atomics
+  int stage;                // bytes per ring stage
+};
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction only takes an immediate)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  switch (n) {
+#define MGD_VMC(k) case k: wait_vmcnt<k>(); break;
+    MGD_VMC(0) MGD_VMC(1) MGD_VMC(2) MGD_VMC(3) MGD_VMC(4) MGD_VMC(5) MGD_VMC(6) MGD_VMC(7) MGD_VMC(8) MGD_VMC(9)
+    MGD_VMC(10) MGD_VMC(11) MGD_VMC(12) MGD_VMC(13) MGD_VMC(14) MGD_VMC(15) MGD_VMC(16) MGD_VMC(17) MGD_VMC(18)
+    MGD_VMC(19) MGD_VMC(20) MGD_VMC(21) MGD_VMC(22) MGD_VMC(23) MGD_VMC(24) MGD_VMC(25) MGD_VMC(26) MGD_VMC(27)
+    MGD_VMC(28) MGD_VMC(29) MGD_VMC(30) MGD_VMC(31) MGD_VMC(32) MGD_VMC(33) MGD_VMC(34) MGD_VMC(35) MGD_VMC(36)
+    MGD_VMC(37) MGD_VMC(38) MGD_VMC(39) MGD_VMC(40) MGD_VMC(41) MGD_VMC(42) MGD_VMC(43) MGD_VMC(44) MGD_VMC(45)
+    MGD_VMC(46) MGD_VMC(47) MGD_VMC(48) MGD_VMC(49) MGD_VMC(50) MGD_VMC(51) MGD_VMC(52) MGD_VMC(53) MGD_VMC(54)
+    MGD_VMC(55) MGD_VMC(56) MGD_VMC(57) MGD_VMC(58) MGD_VMC(59) MGD_VMC(60)
+#undef MGD_VMC
+    default: wait_vmcnt<0>(); break;
+  }
+}
+
+// PPW = patch pieces (1 KiB LDS-DMA wave-instructions) per wave and stage: every wave issues exactly
+// OPW + PPW loads per stage, so the counted vmcnt waits are wave-uniform.
+template <int MT, int NT, int PPW>
+__global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
+  constexpr int BCO = 2 * MT * 16, BCI = 2 * NT * 16;
+  constexpr int RBO = BCO * 2;                 // dy-tile row bytes
+  constexpr int PB = BCI * 2, PBP = PB + 32;   // patch pixel bytes, padded pitch
+  constexpr int ORPI = 1024 / RBO;             // dy rows per 1-KiB piece
+  constexpr int OPW = (64 / ORPI) / 4;         // dy pieces per wave
+  constexpr int LPS = OPW + PPW;               // loads per wave and stage
+  static_assert(OPW >= 1, "dy tile too narrow");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wi = wave & 1;
+  const int tco = blockIdx.x % a.tilesCo, split = blockIdx.x / a.tilesCo;
+  const int co0 = tco * BCO;
+  const int kt0 = split * a.per_split;
+  const int kt1 = min(a.ntiles, kt0 + a.per_split);
+  const void* zero = (const void*)g_zero_page;
+  const int NST = a.nst;
+
+  // ---- per-lane constants of the dy pieces: pixel slot -> (r, c) of the tile, source chunk (tr swizzle as in v2)
+  unsigned dy_off[OPW], dy_rc[OPW];
+#pragma unroll
+  for (int i = 0; i < OPW; ++i) {
+    int p = (i * 4 + wave) * ORPI + lane / (RBO / 16);
+    int o_s = lane % (RBO / 16);
+    int ch = (((o_s >> 1) ^ tr_swz(p, RBO / 32)) << 1) | (o_s & 1);
+    int r = p / a.TW, c = p - r * a.TW;
+    bool ok = r < a.R && co0 + ch * 8 < a.Co;
+    dy_off[i] = (unsigned)((((long long)r * a.Wg + c) * a.Co + co0 + ch * 8) * 2);
+    dy_rc[i] = ok ? ((unsigned)r << 16 | (unsigned)c) : 0x7fff0000u;
+  }
+  // ---- patch pieces: LDS byte -> (patch pixel, 16-byte chunk); chunks >= PB/16 are the pad
+  unsigned p_off[PPW], p_rc[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    int bo = (j * 4 + wave) * 1024 + lane * 16;
+    int pp = bo / PBP, chunk = (bo - pp * PBP) >> 4;
+    int pr = pp / a.PC, pc = pp - pr * a.PC;
+    bool ok = pp < a.PP && chunk < PB / 16;
+    p_off[j] = (unsigned)((((long long)pr * a.Ws + pc) * a.Ci + chunk * 8) * 2);
+    p_rc[j] = ok ? ((unsigned)pr << 16 | (unsigned)pc) : 0x7fff0000u;
+  }
+
+  // next tile to issue (wave-uniform counters instead of divisions per K-step)
+  int in_, ith, itw;
+  {
+    const int tiles_img = a.tilesH * a.tilesW;
+    in_ = kt0 / tiles_img;
+    int rem = kt0 - in_ * tiles_img;
+    ith = rem / a.tilesW;
+    itw = rem - ith * a.tilesW;
+  }
+  auto issue = [&](int buf) {
+    const int h0 = ith * a.R, w0 = itw * a.TW;
+    unsigned char* ob = smem + buf * a.stage;
+    unsigned char* ib = ob + 64 * RBO;
+    const char* dbase = (const char*)a.dy + ((((long long)in_ * a.Hg + h0) * a.Wg + w0) * a.Co) * 2;
+#pragma unroll
+    for (int i = 0; i < OPW; ++i) {
+      int r = (int)(dy_rc[i] >> 16), c = (int)(dy_rc[i] & 0xffffu);
+      bool v = h0 + r < a.Hg && w0 + c < a.Wg;
+      const void* g = v ? (const void*)(dbase + dy_off[i]) : zero;
+      glds16(g, ob + (i * 4 + wave) * 1024);
+    }
+    const int hb = h0 * a.s - 1, wb = w0 * a.s - 1;
+    const char* sbase = (const char*)a.src + ((((long long)in_ * a.Hs + hb) * a.Ws + wb) * a.Ci) * 2;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      int pr = (int)(p_rc[j] >> 16), pc = (int)(p_rc[j] & 0xffffu);
+      bool v = (unsigned)(hb + pr) < (unsigned)a.Hs && (unsigned)(wb + pc) < (unsigned)a.Ws;
+      const void* g = v ? (const void*)(sbase + p_off[j]) : zero;
+      glds16(g, ib + (j * 4 + wave) * 1024);
+    }
+    if (++itw == a.tilesW) {
+      itw = 0;
+      if (++ith == a.tilesH) { ith = 0; ++in_; }
+    }
+  };
+
+  f32x4 acc[9][MT][NT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[t][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment addressing: MFMA k index = pixel slot kk*32 + 8g + qq (+4 for the upper half)
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pl = lane & 3;
+  int o_rd[2][2][MT];   // dy^T fragments  [kk][half][m]
+  int p_rd[2][2];       // patch base      [kk][half]   (+ n*32 + tap offset)
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int p = kk * 32 + 8 * g + qq + 4 * h;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        o_rd[kk][h][m] = p * RBO + (((wc * MT + m) ^ tr_swz(p, RBO / 32)) * 32) + pl * 8;
+      int r = p / a.TW, c = p - r * a.TW;
+      int pp = r < a.R ? (r * a.s + 1) * a.PC + c * a.s + 1 : a.PC + 1;
+      p_rd[kk][h] = 64 * RBO + pp * PBP + wi * NT * 32 + pl * 8;
+    }
+  int toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) toff[t] = ((t / 3 - 1) * a.PC + (t % 3 - 1)) * PBP;
+
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int nkt = kt1 - kt0;
+  int ibuf = 0;           // ring slot of the next issue
+  for (int s = 0; s < NST - 1 && s < nkt; ++s) { issue(ibuf); ibuf = ibuf + 1 == NST ? 0 : ibuf + 1; }
+  int cbuf = 0;           // ring slot being computed
+  // The fragment reads are issued from inline asm: for a ds_read_b64_tr_b16 that the compiler can see it puts
+  // an s_waitcnt vmcnt(0) in front (it cannot tell the read from the LDS-DMA writes in flight), which would
+  // serialise every K-step with the loads of the stages behind it.  With asm the waits are ours: the 18
+  // (k-half, tap) groups of a K-step are software-pipelined DEPTH groups ahead with counted lgkmcnt.
+  constexpr int DEPTH = MT * NT >= 4 ? 2 : 3;
+  constexpr int NG = 18;
+  const unsigned smem_a = lds_addr(smem);
+  for (int it = 0; it < nkt; ++it) {
+    const int ahead = min(NST - 2, nkt - 1 - it);     // younger stages that may stay in flight
+    wait_vmcnt_dyn(ahead * LPS);
+    __builtin_amdgcn_s_barrier();
+    if (it + NST - 1 < nkt) { issue(ibuf); ibuf = ibuf + 1 == NST ? 0 : ibuf + 1; }
+    const unsigned sb = smem_a + cbuf * a.stage;
+    cbuf = cbuf + 1 == NST ? 0 : cbuf + 1;
+
+    s16x4 ofr[2][MT][2];            // dy^T fragments [kk][m][half]
+    s16x4 xbr[DEPTH + 1][NT][2];    // patch fragments, ring over groups
+    auto readA = [&](int kk) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        tr_read_asm<0>(ofr[kk][m][0], sb + o_rd[kk][0][m]);
+        tr_read_asm<0>(ofr[kk][m][1], sb + o_rd[kk][1][m]);
+      }
+    };
+    auto readB = [&](int gi) {
+      const int kk = gi / 9, t = gi % 9, slot = gi % (DEPTH + 1);
+      const unsigned alo = sb + p_rd[kk][0] + toff[t], ahi = sb + p_rd[kk][1] + toff[t];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        if (n == 0) { tr_read_asm<0>(xbr[slot][n][0], alo); tr_read_asm<0>(xbr[slot][n][1], ahi); }
+        else        { tr_read_asm<32>(xbr[slot][n][0], alo); tr_read_asm<32>(xbr[slot][n][1], ahi); }
+      }
+    };
+    readA(0);
+#pragma unroll
+    for (int gi = 0; gi < DEPTH; ++gi) readB(gi);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int kk = gi / 9, t = gi % 9, slot = gi % (DEPTH + 1);
+      if (gi + DEPTH < NG) {
+        if (gi + DEPTH == 9) readA(1);
+        readB(gi + DEPTH);
+      }
+      // LDS operations issued after group gi's reads: the younger B groups, and the kk = 1 dy fragments if
+      // they went out after this group's reads (gi < 9) and have gone out already (gi + DEPTH >= 9)
+      const int younger = (NG - 1 - gi < DEPTH ? NG - 1 - gi : DEPTH) * 2 * NT + ((gi < 9 && gi + DEPTH >= 9) ? 2 * MT : 0);
+      wait_lgkm_dyn(younger);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { touch(xbr[slot][n][0]); touch(xbr[slot][n][1]); }
+      if (t == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { touch(ofr[kk][m][0]); touch(ofr[kk][m][1]); }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        s16x8 av = __builtin_shufflevector(ofr[kk][m][0], ofr[kk][m][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          s16x8 bv = __builtin_shufflevector(xbr[slot][n][0], xbr[slot][n][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[t][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                __builtin_bit_cast(bf16x8, bv), acc[t][m][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  if (a.dbg & 16) { if (acc[0][0][0][0] == 123.456f) a.dw[0] = 1.f; return; }
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int co = co0 + (wc * MT + m) * 16 + fq * 4 + r;
+          int ci = (wi * NT + n) * 16 + fr;
+          if (co < a.Co && ci < a.Ci) atomicAdd(a.dw + ((long long)co * 9 + t) * a.Ci + ci, acc[t][m][n][r]);
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1518,6 +1807,30 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   return 0;
 }
 
+template <int MT, int NT, int PPW>
+int launch_wgrad3(Wgrad3Args& a, hipStream_t st) {
+  constexpr int BCO = 2 * MT * 16;
+  a.tilesCo = cdiv(a.Co, BCO);
+  a.stage = 64 * BCO * 2 + 4 * PPW * 1024;
+  constexpr int OPW = (64 / (1024 / (BCO * 2))) / 4;
+  // measured: two blocks per CU win for Ci = 32 (short MFMA phases), one block with a deep ring for Ci = 64
+  int per_cu = (NT == 1 && 2 * a.stage <= 78 * 1024) ? 2 : 1;
+  a.nst = std::min(6, ((per_cu == 2 ? 78 : 156) * 1024) / a.stage);           // ring as deep as LDS allows
+  while (a.nst > 2 && (a.nst - 2) * (OPW + PPW) > 60) --a.nst;   // vmcnt is a 6-bit counter
+  size_t lds = (size_t)a.nst * a.stage;
+  int splits = std::max(1, 256 * per_cu / a.tilesCo);
+  a.per_split = cdiv(a.ntiles, splits);
+  splits = cdiv(a.ntiles, a.per_split);
+  auto k = conv_wgrad3_kernel<MT, NT, PPW>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(a.tilesCo * splits), dim3(256), lds, st, a);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
@@ -1559,11 +1872,13 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     variant = e ? atoi(e) : 3;
   }
   const int nk = d->K_pad / BK;
-  MGD_REQUIRE(!d->bn_y || variant == 3, "conv: the fused BN-backward reduction needs the default gemm variant (MGD_GEMM=3)");
+  MGD_REQUIRE(!d->bn_y || variant == 3 || variant == 7, "conv: the fused BN-backward reduction needs the default gemm variant (MGD_GEMM=3)");
   if (variant == 1) {
     if (d->Co_pad % 128 == 0) launch_gemm<2, 2, 4, 4>(a, st);
     else if (d->Co_pad % 64 == 0) launch_gemm<1, 4, 4, 2>(a, st);
     else launch_gemm<1, 4, 2, 2>(a, st);
+  } else if (variant == 7 && d->Co_pad % 128 == 0 && !d->dst_f32 && !d->bn_y) {
+    launch_gemm3<2, 2, 4, 4, 4>(a, st);      // experiment: 128x128 tile, BK = 32, 4-stage ring (2 K-steps in flight), 2 blocks/CU
   } else if (variant == 6 && d->Co_pad % 128 == 0 && !d->dst_f32 && (long long)a.M * (d->Co_pad / 128) >= 256ll * 400) {
     launch_gemm3<2, 2, 4, 8, 3>(a, st);      // 128 cout x 256 pixels, 128x64 wave tiles, BK = 32, 3-stage ring
   } else if (variant == 5 && d->Co_pad % 64 == 0 && (long long)a.M * (d->Co_pad / (d->Co_pad % 128 == 0 ? 128 : 64)) >= 256ll * 200 && !d->dst_f32) {
@@ -1605,6 +1920,29 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
   a.rcp_w = 1.0f / (float)d->Wg;
   hipStream_t st = (hipStream_t)stream;
   int co = d->Co, ci = d->Ci;
+  static int wvariant = -1;
+  if (wvariant < 0) { const char* e = getenv("MGD_WGRAD"); wvariant = e ? atoi(e) : 3; }
+  // patch form: 3x3 in the standard tap order, Ci = 32 or 64, output map at least 16 wide
+  bool std9 = d->ntaps == 9;
+  for (int t = 0; t < 9 && std9; ++t) std9 = d->dh[t] == t / 3 - 1 && d->dw_off[t] == t % 3 - 1;
+  if (wvariant == 3 && std9 && (ci == 32 || ci == 64) && co >= 32 && d->Wg >= 16 &&
+      (d->in_stride == 1 || d->in_stride == 2) && d->Hs == d->Hg * d->in_stride && d->Ws == d->Wg * d->in_stride &&
+      (long long)d->N * cdiv(d->Hg, 4) * cdiv(d->Wg, 16) * cdiv(co, 64) >= 256 * 16) {   // >= 16 K-steps per block
+    Wgrad3Args w;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MGD_DBG"); dbg = e ? atoi(e) : 0; } w.dbg = dbg; }
+    w.src = a.src; w.dy = a.dy; w.dw = a.dw;
+    w.N = d->N; w.Hs = d->Hs; w.Ws = d->Ws; w.Ci = ci; w.Hg = d->Hg; w.Wg = d->Wg; w.Co = co;
+    w.s = d->in_stride; w.R = 4; w.TW = 16;
+    w.PC = (w.TW - 1) * w.s + 3;
+    w.PP = ((w.R - 1) * w.s + 3) * w.PC;
+    w.tilesH = cdiv(w.Hg, w.R); w.tilesW = cdiv(w.Wg, w.TW);
+    w.ntiles = w.N * w.tilesH * w.tilesW;
+    // patch pieces per wave = ceil(PP * pitch / 4096): 108 or 297 pixels at 96 / 160 bytes
+    if (ci == 32) { if (w.s == 1) launch_wgrad3<2, 1, 3>(w, st); else launch_wgrad3<2, 1, 7>(w, st); }
+    else          { if (w.s == 1) launch_wgrad3<2, 2, 5>(w, st); else launch_wgrad3<2, 2, 12>(w, st); }
+    MGD_CHECK_LAUNCH("conv_wgrad3");
+    return MGD_OK;
+  }
   if (co > 64 && ci > 64) launch_wgrad<2, 2, 4, 4>(a, st);
   else if (co > 32 && ci > 32) launch_wgrad<2, 2, 2, 2>(a, st);
   else if (ci <= 32) launch_wgrad<2, 2, 2, 1>(a, st);

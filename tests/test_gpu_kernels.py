@@ -52,6 +52,8 @@ CONV_CASES = [
     (8, 96, 96, 64, 128, 3, 1),          # enough tiles for the 8-wave / 256-pixel-tile variant
     (4, 128, 128, 32, 64, 3, 2),
     (6, 100, 100, 128, 64, 1, 1),
+    (2, 40, 36, 32, 64, 3, 1),           # patch-form weight gradient: Ci = 32, ragged tiles
+    (2, 44, 40, 64, 128, 3, 2),          # patch-form weight gradient: Ci = 64, stride 2, ragged tiles
 ]
 
 
