@@ -626,6 +626,329 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Epilogue shared by the gather-GEMM kernels: accumulators -> LDS tile -> whole NHWC rows, with bias, fp32
+// output, the residual-gradient addend, and the two per-channel reductions that ride on the output loop
+// (BatchNorm batch statistics in the forward pass; the BatchNorm-backward sums of the consumer layer in the
+// data gradient).  prefetch() fetches the HBM operands of the bf16 epilogue before the K-loop.
+template <int WC, int WP, int MT, int NT>
+struct GemmEpilogue {
+  static constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16, NTHR = 64 * WC * WP;
+  static constexpr int CPB = BNC / 8;            // 16-byte bf16 chunks per output row
+  static constexpr int EPC = BMP * CPB / NTHR;   // chunks per thread
+  static_assert(BMP * CPB % NTHR == 0 && NTHR % CPB == 0, "epilogue mapping");
+  uint4 ypre[EPC], apre[EPC];
+  float bnp[4][8];
+  bool bnred, addpre;
+
+  __device__ __forceinline__ void prefetch(const GemmArgs& a, const long long* row_dst, int co0, int tid) {
+    bnred = a.bn_y != nullptr && !a.dst_f32;
+    addpre = a.addend != nullptr && !a.dst_f32;
+    if (bnred) {
+      const int c = co0 + (tid % CPB) * 8;
+      const float* ps[4] = {a.bn_scale, a.bn_shift, a.bn_mean, a.bn_invstd};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+        if (c < a.Co) { lo = *(const f32x4*)(ps[k] + c); hi = *(const f32x4*)(ps[k] + c + 4); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bnp[k][j] = lo[j]; bnp[k][4 + j] = hi[j]; }
+      }
+    }
+    if (bnred || addpre) {
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < EPC; ++it) {
+        const int q = tid + it * NTHR;
+        const int r = q / CPB, ch = q - r * CPB;
+        const long long off = row_dst[r];
+        const int c = co0 + ch * 8;
+        const bool ok = off >= 0 && c < a.Co;
+        ypre[it] = (bnred && ok) ? *(const uint4*)(a.bn_y + off + c) : make_uint4(0, 0, 0, 0);
+        apre[it] = (addpre && ok) ? *(const uint4*)(a.addend + off + c) : make_uint4(0, 0, 0, 0);
+      }
+    }
+  }
+
+  // call after a __syncthreads() that follows the last LDS read of the K-loop
+  __device__ __forceinline__ void run(const GemmArgs& a, f32x4 (&acc)[MT][NT], unsigned char* smem,
+                                      const long long* row_dst, int co0, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / WP, wp = wave % WP;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int esz = a.dst_f32 ? 4 : 2;
+    const int EROW = BNC * esz + 16;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      int cl = (wc * MT + m) * 16 + fq * 4;
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      if (a.bias) {
+        int c = co0 + cl;
+        if (c + 3 < a.Co) { b0 = a.bias[c]; b1 = a.bias[c + 1]; b2 = a.bias[c + 2]; b3 = a.bias[c + 3]; }
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        int pl = (wp * NT + n) * 16 + fr;
+        f32x4 v = acc[m][n];
+        v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+        if (a.dst_f32) {
+          *(f32x4*)(smem + pl * EROW + cl * 4) = v;
+        } else {
+          uint2 p;
+          p.x = pack2bf(v[0], v[1]);
+          p.y = pack2bf(v[2], v[3]);
+          *(uint2*)(smem + pl * EROW + cl * 2) = p;
+        }
+      }
+    }
+    __syncthreads();
+    const int CPR = BNC * esz / 16;
+    if (a.dst_f32) {
+      for (int q = tid; q < BMP * CPR; q += NTHR) {
+        int r = q / CPR, ch = q - r * CPR;
+        long long off = row_dst[r];
+        int c = co0 + ch * 4;
+        if (off < 0 || c >= a.Co) continue;
+        *(uint4*)((float*)a.dst + off + c) = *(const uint4*)(smem + r * EROW + ch * 16);
+      }
+      return;
+    }
+    const bool stats = a.stats != nullptr;
+    float r1[8], r2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r1[j] = r2[j] = 0.f;
+#pragma unroll
+    for (int it = 0; it < EPC; ++it) {
+      const int q = tid + it * NTHR;
+      const int r = q / CPB, ch = q - r * CPB;
+      const long long off = row_dst[r];
+      const int c = co0 + ch * 8;
+      if (off < 0 || c >= a.Co) continue;
+      uint4 v = *(const uint4*)(smem + r * EROW + ch * 16);
+      if (addpre) {
+        float f[8], g[8];
+        unpack8(v, f);
+        unpack8(apre[it], g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += g[j];
+        v = pack8(f);
+      }
+      *(uint4*)((bf16_t*)a.dst + off + c) = v;
+      if (stats) {
+        float d[8];
+        unpack8(v, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { r1[j] += d[j]; r2[j] = fmaf(d[j], d[j], r2[j]); }
+      } else if (bnred) {
+        float d[8], yv[8];
+        unpack8(v, d);
+        unpack8(ypre[it], yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float z = fmaf(yv[j], bnp[0][j], bnp[1][j]);
+          float dd = z > 0.f ? d[j] : d[j] * a.bn_slope;
+          r1[j] += dd;
+          r2[j] = fmaf(dd * (yv[j] - bnp[2][j]), bnp[3][j], r2[j]);
+        }
+      }
+    }
+    if (stats || bnred) {
+      float* wred = (float*)(smem + BMP * (BNC * 2 + 16));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int o = CPB; o < 64; o <<= 1) { r1[j] += __shfl_xor(r1[j], o, 64); r2[j] += __shfl_xor(r2[j], o, 64); }
+      }
+      if (lane < CPB) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          wred[wave * 2 * BNC + lane * 8 + j] = r1[j];
+          wred[wave * 2 * BNC + BNC + lane * 8 + j] = r2[j];
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * BNC) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NTHR / 64; ++w) t += wred[w * 2 * BNC + tid];
+        int which = tid / BNC, col = tid - which * BNC;
+        if (co0 + col < a.Co) {
+          int rep = blockIdx.x % a.stats_replicas;
+          float* dstp = stats ? a.stats : a.bn_sums;
+          atomicAdd(dstp + ((long long)rep * 2 + which) * a.Co + co0 + col, t);
+        }
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// v4, "row-shift" form of the 3x3 stride-1 gather-GEMM (forward and stride-1 data gradient).  The three taps
+// (dh, -1), (dh, 0), (dh, +1) of one 64-channel chunk gather the SAME 128 flattened pixels shifted by one pixel,
+// so the pixel tile is staged once per (dh, chunk) as 130 rows (pixels pix0-1 .. pix0+128 of input row h+dh)
+// and the three K-steps read it at row offsets 0/1/2: LDS-DMA bytes per K-step fall from 32 KB to 21.7 KB
+// (the kernel is bound by the per-CU L2->LDS rate, not by MFMA).  Lanes whose pixel sits on the left/right
+// image border read a zero row for the dw = -1 / +1 step instead.  Weight tiles keep the 2-stage ring of v2.
+// LDS: W ring 2 x BNC rows | X0 | X1 (137 rows each: 136 DMA rows + 1 zero row) | row_dst.
+template <int WC, int WP, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_gemm4_kernel(GemmArgs a) {
+  using Epi = GemmEpilogue<WC, WP, MT, NT>;
+  constexpr int BNC = WC * MT * 16;
+  constexpr int BMP = WP * NT * 16;
+  static_assert(WC * WP == 4 && BMP == 128, "4 waves, 128-pixel tile");
+  constexpr int WCH = BNC / 32;                 // weight LDS-DMA pieces per wave per K-step
+  constexpr int WST = BNC * ROWB;               // bytes per weight stage
+  constexpr int XROWS = 137, XZ = 136;          // pixel-buffer rows, index of the zero row
+  constexpr int XBUF = XROWS * ROWB;
+  constexpr int XP = 17;                        // 1-KiB pieces per pixel buffer (rows 0..135)
+  constexpr int RING = 2 * WST + 2 * XBUF;
+  constexpr int EPI_MAX = BMP * (BNC * 4 + 16);
+  constexpr int AUX = RING > EPI_MAX ? RING : EPI_MAX;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  long long* row_dst = (long long*)(smem + AUX);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave / WP, wp = wave % WP;
+  const int L = xcd_remap(blockIdx.x, a.nblk);
+  const int tc = L % a.tilesC, tp = L / a.tilesC;
+  const int co0 = tc * BNC;
+  const int pix0 = tp * BMP;
+  const int hw = a.Hg * a.Wg;
+
+  if (tid < BMP) {
+    int m = pix0 + tid;
+    long long off = -1;
+    if (m < a.M) {
+      int n = m / hw, rem = m - n * hw;
+      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+      off = (((long long)n * a.Hd + ig) * a.Wd + jg) * a.Co;
+    }
+    row_dst[tid] = off;
+  }
+  if (tid < 16) {   // the zero rows
+    *(uint4*)(smem + 2 * WST + XZ * ROWB + (tid & 7) * 16 + (tid >> 3) * XBUF) = make_uint4(0, 0, 0, 0);
+  }
+  Epi epi;
+  epi.prefetch(a, row_dst, co0, tid);
+
+  // ---- weight pieces: thread -> slot (tid & 7) of rows (tid >> 3) + 32 i, source chunk kc = slot ^ (row & 7)
+  const int rlo = tid >> 3;
+  const int kc = (tid & 7) ^ (rlo & 7);
+  unsigned woff[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) woff[i] = (unsigned)(((long long)(co0 + rlo + 32 * i) * a.K_pad + kc * 8) * 2);
+  const char* wbase = (const char*)a.wpk;
+
+  // ---- pixel pieces: piece p (rows 8p..8p+7 of the buffer, row r <-> flattened pixel pix0 - 1 + r) is issued by
+  // wave p % 4; per piece a byte offset of the un-shifted pixel and a 3-bit mask "input row h+dh exists"
+  constexpr int XPW = (XP + 3) / 4;             // pieces per wave (5, the last one only on wave 0)
+  unsigned xoff[XPW], xmask[XPW];
+#pragma unroll
+  for (int j = 0; j < XPW; ++j) {
+    int p = j * 4 + wave;
+    int r = p * 8 + (lane >> 3);
+    int m = pix0 - 1 + r;
+    xoff[j] = 0; xmask[j] = 0;
+    if (p < XP && r < 130 && m >= 0 && m < a.M) {
+      int n = m / hw, rem = m - n * hw;
+      int ig = rem / a.Wg;
+      int slot = lane & 7;
+      xoff[j] = (unsigned)(((long long)m * a.Ci + ((slot ^ (r & 7)) * 8)) * 2);
+      xmask[j] = (ig > 0 ? 1u : 0u) | 2u | (ig + 1 < a.Hg ? 4u : 0u);
+    }
+  }
+  const char* xbase = (const char*)a.src;
+  const void* zero = (const void*)g_zero_page;
+  const int rowbytes = a.Wg * a.Ci * 2;
+  const int nch = a.Ci / BK;                    // 64-channel chunks
+  const int nbt = 3 * nch;                      // pixel tiles: (dh, chunk)
+  const int nsteps = 3 * nbt;
+
+  auto issue_w = [&](int step, int buf) {       // step = (dh*nch + cc)*3 + dwi
+    int bt = step / 3, dwi = step - bt * 3;
+    int dhi = bt / nch, cc = bt - dhi * nch;
+    unsigned k0 = (unsigned)(((dhi * 3 + dwi) * a.Ci + cc * BK) * 2);
+    unsigned char* wb = smem + buf * WST + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) glds16(wbase + woff[i] + k0, wb + i * (32 * ROWB));
+  };
+  auto issue_x = [&](int bt, int part) {        // third `part` (0..2) of pixel tile bt into buffer bt & 1
+    int dhi = bt / nch, cc = bt - dhi * nch;
+    long long shift = (long long)(dhi - 1) * rowbytes + cc * (BK * 2);
+    unsigned char* xb = smem + 2 * WST + (bt & 1) * XBUF;
+#pragma unroll
+    for (int j = 0; j < XPW; ++j) {
+      int p = j * 4 + wave;
+      if (p < XP && p / 6 == part) {
+        bool v = (xmask[j] >> dhi) & 1u;
+        const void* g = v ? (const void*)(xbase + xoff[j] + shift) : zero;
+        glds16(g, xb + p * 1024);
+      }
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int wro[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) wro[m] = lds_off((wc * MT + m) * 16 + fr, fq);
+  // my pixels: row in the buffer for dw = 0 is pl + 1; border flags select the zero row for dw = -1 / +1
+  int prow[NT];
+  unsigned bflag = 0;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    int pl = (wp * NT + n) * 16 + fr;
+    prow[n] = pl + 1;
+    int m = pix0 + pl;
+    int jg = m % a.Wg;
+    if (jg == 0) bflag |= 1u << (2 * n);
+    if (jg == a.Wg - 1) bflag |= 2u << (2 * n);
+  }
+
+  // prologue: first pixel tile (all three parts) and the first weight stage
+  issue_x(0, 0); issue_x(0, 1); issue_x(0, 2);
+  issue_w(0, 0);
+  int bt = 0, dwi = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (s + 1 < nsteps) issue_w(s + 1, (s + 1) & 1);
+    if (bt + 1 < nbt) issue_x(bt + 1, dwi);
+    const unsigned char* wb = smem + (s & 1) * WST;
+    const unsigned char* xb = smem + 2 * WST + (bt & 1) * XBUF;
+    int xro[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      int r = prow[n] + dwi - 1;
+      bool z = (dwi == 0 && ((bflag >> (2 * n)) & 1u)) || (dwi == 2 && ((bflag >> (2 * n)) & 2u));
+      r = z ? XZ : r;
+      xro[n] = r * ROWB + ((fq ^ (r & 7)) << 4);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 wf[MT], xf[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(wb + (wro[m] ^ (kk << 6)));
+#pragma unroll
+      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(xb + (xro[n] ^ (kk << 6)));
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
+    }
+    if (++dwi == 3) { dwi = 0; ++bt; }
+  }
+  __syncthreads();
+  epi.run(a, acc, smem, row_dst, co0, tid);
+}
+
 template <int WC, int WP, int MT, int NT, int NST>
 __global__ __launch_bounds__(64 * WC * WP) void conv_gemm3_kernel(GemmArgs a) {
   // BK = 32 variant: tile rows are 64 B (4 chunks of 16 B), chunk c of row r stored at slot c ^ g((r>>2)&3)
@@ -1749,6 +2072,24 @@ int launch_gemm2(GemmArgs& a, hipStream_t st) {
 }
 
 
+template <int WC, int WP, int MT, int NT>
+int launch_gemm4(GemmArgs& a, hipStream_t st) {
+  constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
+  a.tilesC = a.Co_pad / BNC;
+  a.nblk = a.tilesC * cdiv(a.M, BMP);
+  size_t ring = (size_t)2 * BNC * ROWB + (size_t)2 * 137 * ROWB;     // must match RING / AUX in the kernel
+  size_t epi = (size_t)BMP * (BNC * 4 + 16);
+  size_t lds = (ring > epi ? ring : epi) + (size_t)BMP * 8;
+  auto k = conv_gemm4_kernel<WC, WP, MT, NT>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), lds, st, a);
+  return 0;
+}
+
 template <int WC, int WP, int MT, int NT, int NST>
 int launch_gemm3(GemmArgs& a, hipStream_t st) {
   constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
@@ -1873,6 +2214,20 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   }
   const int nk = d->K_pad / BK;
   MGD_REQUIRE(!d->bn_y || variant == 3 || variant == 7, "conv: the fused BN-backward reduction needs the default gemm variant (MGD_GEMM=3)");
+  // row-shift form: 3x3 in the standard tap order, stride 1, same-size maps, whole 64-channel chunks
+  bool std9 = d->ntaps == 9 && d->in_stride == 1 && d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 &&
+              d->Hs == d->Hg && d->Ws == d->Wg && d->Hd == d->Hg && d->Wd == d->Wg && d->Ci % BK == 0 &&
+              d->K_pad == 9 * d->Ci && (long long)d->N * d->Hs * d->Ws * d->Ci < (1ll << 30);
+  for (int t = 0; t < 9 && std9; ++t) std9 = d->dh[t] == t / 3 - 1 && d->dw[t] == t % 3 - 1;
+  static int rowshift = -1;
+  if (rowshift < 0) { const char* e = getenv("MGD_ROWSHIFT"); rowshift = e ? atoi(e) : 0; }   // opt-in: measured equal to v2 (the K-loop is not bound by LDS-DMA bytes)
+  if (variant == 3 && rowshift && std9) {
+    if (d->Co_pad % 128 == 0) launch_gemm4<2, 2, 4, 4>(a, st);
+    else if (d->Co_pad % 64 == 0) launch_gemm4<1, 4, 4, 2>(a, st);
+    else launch_gemm4<1, 4, 2, 2>(a, st);
+    MGD_CHECK_LAUNCH("conv_gather_gemm(row-shift)");
+    return MGD_OK;
+  }
   if (variant == 1) {
     if (d->Co_pad % 128 == 0) launch_gemm<2, 2, 4, 4>(a, st);
     else if (d->Co_pad % 64 == 0) launch_gemm<1, 4, 4, 2>(a, st);
