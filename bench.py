@@ -97,6 +97,19 @@ def cpu_baseline(size):
                       f"batch 1, {cores} threads, after a 128x128 warm-up step; {dt:.2f} s"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (collected in separate
+    rocprofv3 --pmc passes of this same command; FETCH_SIZE x2 on gfx950 + WRITE_SIZE); (None, reason) if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.txt")
+    try:
+        for line in open(path):
+            if line.startswith("conv_gemm2_kernel<2, 2, 4, 4, 2"):
+                return int(float(line.split("|")[-1]) * 1024 * 1024), "profiles/r01_pmc_traffic.txt (separate --pmc passes)"
+    except OSError:
+        pass
+    return None, "no PMC summary found"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,12 +186,21 @@ def main():
         ms = sum(p[0].elapsed_time(p[1]) for p in prof if p[3] == "gemm128")
         n = sum(1 for p in prof if p[3] == "gemm128")
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # the forward launches run alone on the GPU (the weight gradients only overlap the backward pass)
+        ffl = sum(p[2] for p in prof if p[3] == "gemm128" and p[4] == "conv_fwd")
+        fms = sum(p[0].elapsed_time(p[1]) for p in prof if p[3] == "gemm128" and p[4] == "conv_fwd")
+        fn = sum(1 for p in prof if p[3] == "gemm128" and p[4] == "conv_fwd")
+        fach = ffl / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
+        traffic, tsrc = pmc_traffic()
         roof = {"bound": "mfma", "kernel": "conv_gemm2_kernel<2,2,4,4,2> (128x128-tile bf16 MFMA gather-GEMM: 3x3/1x1 "
                                            "conv forward + data gradient)", "achieved": round(ach, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": None, "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": tsrc, "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                 "event_steps": 1, "share_of_step_time": round(ms / (dt * 1e3 / args.steps), 3),
-                "note": "durations include CU sharing with conv_wgrad2_kernel, which runs concurrently on a side stream",
+                "note": "durations include CU sharing with conv_wgrad2_kernel, which runs concurrently on a side stream "
+                        "during the backward pass; forward_only = the same kernel's forward launches, which run alone",
+                "forward_only": {"achieved": round(fach, 2), "frac": round(fach / PEAK_BF16_TFLOPS, 4), "launches": fn,
+                                 "avg_launch_us": round(1e3 * fms / max(fn, 1), 2)},
                 "whole_step_conv_tflops": round(ips / world * 3 * FLOP_PER_IMAGE_FWD * (args.size / 608) ** 2 / 1e12, 1),
                 "algorithmic_flop_per_launch_avg": round(fl / max(n, 1) / 1e9, 2)}
     out = {

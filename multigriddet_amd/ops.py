@@ -16,7 +16,7 @@ BN_MOMENTUM = 0.99
 LEAKY_SLOPE = 0.1
 STATS_REPLICAS = 16
 # bench.py sets this to a list to bracket every gather-GEMM launch with HIP events on the launch
-# stream: entries are (start_event, end_event, algorithmic_flops, kernel_variant).
+# stream: entries are (start_event, end_event, algorithmic_flops, kernel_variant, pass).
 PROFILE = None
 
 
@@ -30,7 +30,7 @@ def _launch_gemm(d, what):
     L.check(lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), what)
     e1.record()
     variant = "gemm128" if d.Co_pad % 128 == 0 else ("gemm64" if d.Co_pad % 64 == 0 else "gemm32")
-    PROFILE.append((e0, e1, 2.0 * d.N * d.Hg * d.Wg * d.ntaps * d.Ci * d.Co, variant))
+    PROFILE.append((e0, e1, 2.0 * d.N * d.Hg * d.Wg * d.ntaps * d.Ci * d.Co, variant, what))
 
 
 def _ru(x, m):
