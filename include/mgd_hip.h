@@ -247,12 +247,25 @@ int mgd_decode(const mgd_decode_cfg* cfg, const float* const* y_pred_host, const
                float* cand_boxes, float* cand_scores, int32_t* cand_cls, int32_t* cand_count, void* ws,
                size_t ws_bytes, void* stream);
 
-/* method: 0 = standard/cluster (IoU), 1 = DIoU, 2 = soft (sigma 0.5, score thr 1e-3).
+/* method: 0 = standard/cluster (IoU, nms.py:83-148, 320-385), 1 = DIoU (nms.py:151-231),
+ * 2 = soft (nms.py:234-317: sigma 0.5, score threshold 1e-3; `threshold` is ignored, survivors leave in
+ * original candidate order with their decayed scores, or the top max_boxes by decayed score if more survive).
  * out_boxes i32 [B][max_boxes][4] (xyxy, clipped, floor(v+0.5)) or f32 xywh if !return_xyxy;
- * out_count[b] = number of detections. */
+ * out_count[b] = number of detections.  Workspace: mgd_nms_workspace_size(B, cap) bytes. */
 size_t mgd_nms_workspace_size(int B, int cap);
 int mgd_nms(const float* cand_boxes, const float* cand_scores, const int32_t* cand_cls,
             const int32_t* cand_count, int B, int cap, int method, float threshold, int max_boxes,
+            const float* image_hw, int return_xyxy, void* out_boxes, float* out_scores, int32_t* out_cls,
+            int32_t* out_count, void* ws, size_t ws_bytes, void* stream);
+
+/* Weighted Boxes Fusion on one model's detections, as MultiGridDecoder.handle_predictions(use_wbf=True) runs it
+ * (multigriddet/postprocess/wbf.py:79-199 via multigrid_decode.py:281-287, iou_thr = nms_threshold,
+ * skip_box_thr 0, conf_type 'avg'): per class, greedy clusters around the highest-scoring unused box
+ * (IoU against the seed), score-weighted mean box (float64), mean score; output in (class ascending, seed score
+ * descending) order, or the top max_boxes by score if there are more.  Same argument meaning as mgd_nms. */
+size_t mgd_wbf_workspace_size(int B, int cap);
+int mgd_wbf(const float* cand_boxes, const float* cand_scores, const int32_t* cand_cls,
+            const int32_t* cand_count, int B, int cap, float iou_threshold, int max_boxes,
             const float* image_hw, int return_xyxy, void* out_boxes, float* out_scores, int32_t* out_cls,
             int32_t* out_count, void* ws, size_t ws_bytes, void* stream);
 

@@ -178,6 +178,22 @@ __device__ __forceinline__ float pair_metric(const float4 A, const float4 Bx, in
   return iou - cd / (ed + 1e-8f);
 }
 
+// block-wide (1024 threads) bitonic sort of np2 (power of two) 64-bit keys in LDS, descending
+__device__ __forceinline__ void bitonic_desc(unsigned long long* keys, int np2, int tid) {
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < np2; i += 1024) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned long long x = keys[i], y = keys[ixj];
+          bool desc = (i & k) == 0;
+          if (desc ? x < y : x > y) { keys[i] = y; keys[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+}
+
 // one block (1024 threads) per image: bitonic sort by (score, index) descending in LDS, then greedy
 // suppression with an alive bitmask; kept boxes come out in descending score order.
 __global__ __launch_bounds__(1024) void nms_kernel(NmsArgs a) {
@@ -196,18 +212,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(NmsArgs a) {
   for (int i = tid; i < np2; i += 1024)
     keys[i] = i < n ? (((unsigned long long)__float_as_uint(fmaxf(sc[i], 0.f)) << 32) | (unsigned)i) : 0ull;
   __syncthreads();
-  for (int k = 2; k <= np2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < np2; i += 1024) {
-        int ixj = i ^ j;
-        if (ixj > i) {
-          unsigned long long x = keys[i], y = keys[ixj];
-          bool desc = (i & k) == 0;
-          if (desc ? x < y : x > y) { keys[i] = y; keys[ixj] = x; }
-        }
-      }
-      __syncthreads();
-    }
+  bitonic_desc(keys, np2, tid);
   // gather boxes in sorted order (global scratch, L2 resident)
   float* sb = a.sorted + (long long)b * a.cap * 4;
   for (int i = tid; i < n; i += 1024) {
@@ -265,6 +270,237 @@ __global__ __launch_bounds__(1024) void nms_kernel(NmsArgs a) {
     a.out_cls[o] = a.cls[(long long)b * a.cap + src];
   }
 }
+
+__device__ __forceinline__ void write_box(const NmsArgs& a, long long o, double x, double y, double w, double h, float ih,
+                                          float iw) {
+  if (a.return_xyxy) {
+    double x0 = x, y0 = y, x1 = x + w, y1 = y + h;
+    x0 = fmin(fmax(x0, 0.0), (double)iw); y0 = fmin(fmax(y0, 0.0), (double)ih);
+    x1 = fmin(fmax(x1, 0.0), (double)iw); y1 = fmin(fmax(y1, 0.0), (double)ih);
+    int* ob = (int*)a.out_boxes + o * 4;
+    ob[0] = (int)floor(x0 + 0.5); ob[1] = (int)floor(y0 + 0.5);
+    ob[2] = (int)floor(x1 + 0.5); ob[3] = (int)floor(y1 + 0.5);
+  } else {
+    float* ob = (float*)a.out_boxes + o * 4;
+    ob[0] = (float)x; ob[1] = (float)y; ob[2] = (float)w; ob[3] = (float)h;
+  }
+}
+
+// SoftNMS (reference nms.py:234-317; sigma 0.5, score threshold 1e-3): fixed order = scores descending (never
+// re-sorted); box i, unless its own decayed score has fallen below the threshold (then it is zeroed), multiplies
+// the score of every later box by exp(-iou^2 / sigma).  Survivors leave in ORIGINAL candidate order with their
+// decayed scores; if more than max_boxes survive, the top max_boxes by decayed score (postprocess _filter_boxes).
+// ws per image: sorted boxes [cap][4] f32 | soft scores [cap] f32 | original index [cap] i32.
+__global__ __launch_bounds__(1024) void soft_nms_kernel(NmsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* keys = (unsigned long long*)smem;
+  __shared__ int surv;
+  const int b = blockIdx.x;
+  const int n = min(a.count[b], a.cap);
+  const int tid = threadIdx.x;
+  const float* bx = a.boxes + (long long)b * a.cap * 4;
+  const float* sc = a.scores + (long long)b * a.cap;
+  float* sb = a.sorted + (long long)b * a.cap * 6;
+  float* ss = sb + (long long)a.cap * 4;
+  int* so = (int*)(ss + a.cap);
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int i = tid; i < np2; i += 1024)
+    keys[i] = i < n ? (((unsigned long long)__float_as_uint(fmaxf(sc[i], 0.f)) << 32) | (unsigned)i) : 0ull;
+  if (tid == 0) surv = 0;
+  __syncthreads();
+  bitonic_desc(keys, np2, tid);
+  for (int i = tid; i < n; i += 1024) {
+    int src = (int)(keys[i] & 0xffffffffu);
+    *(float4*)(sb + (long long)i * 4) = *(const float4*)(bx + (long long)src * 4);
+    ss[i] = sc[src];
+    so[i] = src;
+  }
+  __threadfence_block();
+  __syncthreads();
+  const float sthr = 0.001f, sigma = 0.5f;
+  for (int i = 0; i < n; ++i) {
+    const float s = ss[i];
+    if (s < sthr) {                 // position i is never touched again inside the loop
+      if (tid == 0) ss[i] = 0.f;
+      continue;
+    }
+    if (i + 1 >= n) break;
+    const float4 cur = *(const float4*)(sb + (long long)i * 4);
+    for (int j = i + 1 + tid; j < n; j += 1024) {
+      float iou = pair_metric(cur, *(const float4*)(sb + (long long)j * 4), 0);
+      ss[j] *= expf(-(iou * iou) / sigma);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  __syncthreads();
+  int mine = 0;
+  for (int i = tid; i < n; i += 1024) mine += ss[i] >= sthr ? 1 : 0;
+  if (mine) atomicAdd(&surv, mine);
+  __syncthreads();
+  const int K = surv;
+  const bool by_score = K > a.max_boxes;
+  for (int i = tid; i < np2; i += 1024) {
+    unsigned long long k = 0ull;
+    if (i < n && ss[i] >= sthr) {
+      unsigned hi = by_score ? __float_as_uint(ss[i]) : (0x7fffffffu - (unsigned)so[i]);
+      k = ((unsigned long long)hi << 32) | (unsigned)(i + 1);
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  bitonic_desc(keys, np2, tid);
+  const int Ko = min(K, a.max_boxes);
+  if (tid == 0) a.out_count[b] = Ko;
+  const float ih = a.image_hw[b * 2], iw = a.image_hw[b * 2 + 1];
+  for (int k = tid; k < Ko; k += 1024) {
+    int i = (int)(keys[k] & 0xffffffffu) - 1;
+    int src = so[i];
+    float4 B4 = *(const float4*)(bx + (long long)src * 4);
+    long long o = (long long)b * a.max_boxes + k;
+    write_box(a, o, B4.x, B4.y, B4.z, B4.w, ih, iw);
+    a.out_scores[o] = ss[i];
+    a.out_cls[o] = a.cls[(long long)b * a.cap + src];
+  }
+}
+
+// Weighted Boxes Fusion as the reference runs it on one model's detections (wbf.py:79-199, called from
+// multigrid_decode.py:281-287 with iou_thr = nms_threshold): per class (ascending id), boxes in descending score
+// order; the first unused box seeds a cluster and every later unused box of the class with IoU(seed, box) >= thr
+// joins it (IoU against the SEED, fp32, no epsilon, 0 when the boxes do not overlap).  Cluster box = score-weighted
+// mean (float64 in the reference), cluster score = mean score.  More than max_boxes clusters -> top max_boxes by
+// score.  ws per image: sorted boxes [cap][4] f32 | scores [cap] f32 | class [cap] i32 | cluster box [cap][4] f64 |
+// cluster score [cap] f32 | cluster class [cap] i32.
+__device__ __forceinline__ float wbf_iou(const float4 A, const float4 Bx) {
+  float ixmin = fmaxf(A.x, Bx.x), iymin = fmaxf(A.y, Bx.y);
+  float ixmax = fminf(A.x + A.z, Bx.x + Bx.z), iymax = fminf(A.y + A.w, Bx.y + Bx.w);
+  if (ixmax <= ixmin || iymax <= iymin) return 0.0f;
+  float inter = (ixmax - ixmin) * (iymax - iymin);
+  float uni = A.z * A.w + Bx.z * Bx.w - inter;
+  return uni > 0.f ? inter / uni : 0.0f;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    long long bits = __double_as_longlong(v);
+    int lo = __shfl_xor((int)(bits & 0xffffffffll), o, 64), hi = __shfl_xor((int)(bits >> 32), o, 64);
+    v += __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void wbf_kernel(NmsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* keys = (unsigned long long*)smem;
+  unsigned int* alive = (unsigned int*)(smem + (size_t)a.npow2 * 8);
+  __shared__ double part[16][6];
+  const int b = blockIdx.x;
+  const int n = min(a.count[b], a.cap);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* bx = a.boxes + (long long)b * a.cap * 4;
+  const float* sc = a.scores + (long long)b * a.cap;
+  const int* cl = a.cls + (long long)b * a.cap;
+  unsigned char* wsb = (unsigned char*)a.sorted + (long long)b * a.cap * 64;
+  float* sb = (float*)wsb;
+  float* ss = sb + (long long)a.cap * 4;
+  int* scl = (int*)(ss + a.cap);
+  double* cb = (double*)(wsb + (long long)a.cap * 24);
+  float* cs = (float*)(wsb + (long long)a.cap * 56);
+  int* cc = (int*)(wsb + (long long)a.cap * 60);
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int i = tid; i < np2; i += 1024) {
+    unsigned long long k = 0ull;
+    if (i < n) {
+      unsigned c = (unsigned)min(max(cl[i], 0), 65534);
+      k = ((unsigned long long)(65535u - c) << 48) | ((unsigned long long)__float_as_uint(fmaxf(sc[i], 0.f)) << 16) |
+          (unsigned long long)(i & 0xffff);
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  bitonic_desc(keys, np2, tid);
+  for (int i = tid; i < n; i += 1024) {
+    int src = (int)(keys[i] & 0xffffull);
+    *(float4*)(sb + (long long)i * 4) = *(const float4*)(bx + (long long)src * 4);
+    ss[i] = sc[src];
+    scl[i] = cl[src];
+  }
+  const int nw = (n + 31) >> 5;
+  for (int i = tid; i < nw; i += 1024) {
+    int rem = n - i * 32;
+    alive[i] = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+  }
+  __threadfence_block();
+  __syncthreads();
+  int i = 0, K = 0;
+  while (true) {
+    int w = i >> 5;
+    unsigned int m = w < nw ? (alive[w] & (0xffffffffu << (i & 31))) : 0u;
+    while (!m && ++w < nw) m = alive[w];
+    if (!m) break;
+    i = w * 32 + __ffs(m) - 1;
+    __syncthreads();                       // everyone has read alive[] before it changes
+    const float4 seed = *(const float4*)(sb + (long long)i * 4);
+    const int c = scl[i];
+    double acc[6] = {0, 0, 0, 0, 0, 0};    // sum s*x, s*y, s*w, s*h, sum s, count
+    if (tid == 0) {
+      double s0 = (double)ss[i];
+      acc[0] = s0 * seed.x; acc[1] = s0 * seed.y; acc[2] = s0 * seed.z; acc[3] = s0 * seed.w; acc[4] = s0; acc[5] = 1.0;
+    }
+    for (int j = i + 1 + tid; j < n; j += 1024) {
+      if (scl[j] != c) break;              // classes are contiguous in the sorted order
+      if (alive[j >> 5] & (1u << (j & 31))) {
+        float4 o = *(const float4*)(sb + (long long)j * 4);
+        if (wbf_iou(seed, o) >= a.thr) {
+          atomicAnd(&alive[j >> 5], ~(1u << (j & 31)));
+          double sj = (double)ss[j];
+          acc[0] += sj * o.x; acc[1] += sj * o.y; acc[2] += sj * o.z; acc[3] += sj * o.w; acc[4] += sj; acc[5] += 1.0;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      double v = wave_sum_f64(acc[q]);
+      if (lane == 0) part[wave][q] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double t[6] = {0, 0, 0, 0, 0, 0};
+      for (int wv = 0; wv < 16; ++wv)
+        for (int q = 0; q < 6; ++q) t[q] += part[wv][q];
+      cb[(long long)K * 4 + 0] = t[0] / t[4]; cb[(long long)K * 4 + 1] = t[1] / t[4];
+      cb[(long long)K * 4 + 2] = t[2] / t[4]; cb[(long long)K * 4 + 3] = t[3] / t[4];
+      cs[K] = (float)(t[4] / t[5]);
+      cc[K] = c;
+    }
+    ++K;
+    ++i;
+    __threadfence_block();
+    __syncthreads();
+  }
+  // clusters are in (class ascending, seed score descending) order = the reference's output order
+  const float ih = a.image_hw[b * 2], iw = a.image_hw[b * 2 + 1];
+  const int Ko = min(K, a.max_boxes);
+  if (tid == 0) a.out_count[b] = Ko;
+  if (K > a.max_boxes) {
+    int kp2 = 1;
+    while (kp2 < K) kp2 <<= 1;
+    for (int k = tid; k < kp2; k += 1024)
+      keys[k] = k < K ? (((unsigned long long)__float_as_uint(fmaxf(cs[k], 0.f)) << 32) | (unsigned)k) : 0ull;
+    __syncthreads();
+    bitonic_desc(keys, kp2, tid);
+  }
+  for (int k = tid; k < Ko; k += 1024) {
+    int src = K > a.max_boxes ? (int)(keys[k] & 0xffffffffu) : k;
+    long long o = (long long)b * a.max_boxes + k;
+    write_box(a, o, cb[(long long)src * 4], cb[(long long)src * 4 + 1], cb[(long long)src * 4 + 2], cb[(long long)src * 4 + 3],
+              ih, iw);
+    a.out_scores[o] = cs[src];
+    a.out_cls[o] = cc[src];
+  }
+}
 #pragma clang fp contract(fast)
 
 size_t dec_ws(const mgd_decode_cfg* c, size_t* o_scores, size_t* o_cls) {
@@ -315,7 +551,7 @@ extern "C" int mgd_decode(const mgd_decode_cfg* cfg, const float* const* y_pred_
   return MGD_OK;
 }
 
-extern "C" size_t mgd_nms_workspace_size(int B, int cap) { return (size_t)B * cap * 16; }
+extern "C" size_t mgd_nms_workspace_size(int B, int cap) { return (size_t)B * cap * 24; }   // soft: + score + index
 
 extern "C" int mgd_nms(const float* cand_boxes, const float* cand_scores, const int32_t* cand_cls,
                        const int32_t* cand_count, int B, int cap, int method, float threshold, int max_boxes,
@@ -324,10 +560,10 @@ extern "C" int mgd_nms(const float* cand_boxes, const float* cand_scores, const 
   MGD_REQUIRE(cand_boxes && cand_scores && cand_cls && cand_count && image_hw && out_boxes && out_scores && out_cls &&
                   out_count && ws,
               "nms: null pointer");
-  MGD_REQUIRE(method == 0 || method == 1, "nms: method %d not supported by the device path (0=iou, 1=diou)", method);
+  MGD_REQUIRE(method >= 0 && method <= 2, "nms: method %d unknown (0=iou, 1=diou, 2=soft)", method);
   MGD_REQUIRE(max_boxes >= 1 && max_boxes <= 1024, "nms: max_boxes=%d must be in [1,1024]", max_boxes);
   MGD_REQUIRE(cap >= 1 && cap <= 16384, "nms: cap=%d must be in [1,16384]", cap);
-  if (ws_bytes < (size_t)B * cap * 16) return mgd_set_error(MGD_ENOSPC, "nms: workspace too small");
+  if (ws_bytes < (size_t)B * cap * 24) return mgd_set_error(MGD_ENOSPC, "nms: workspace too small");
   NmsArgs a;
   a.boxes = cand_boxes; a.scores = cand_scores; a.cls = cand_cls; a.count = cand_count;
   a.B = B; a.cap = cap; a.method = method; a.max_boxes = max_boxes; a.return_xyxy = return_xyxy; a.thr = threshold;
@@ -342,7 +578,47 @@ extern "C" int mgd_nms(const float* cand_boxes, const float* cand_scores, const 
     (void)hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, a);
+  if (method == 2) {
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute((const void*)soft_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(soft_nms_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, a);
+  }
   MGD_CHECK_LAUNCH("nms");
+  return MGD_OK;
+}
+
+extern "C" size_t mgd_wbf_workspace_size(int B, int cap) { return (size_t)B * cap * 64; }
+
+extern "C" int mgd_wbf(const float* cand_boxes, const float* cand_scores, const int32_t* cand_cls,
+                       const int32_t* cand_count, int B, int cap, float iou_threshold, int max_boxes,
+                       const float* image_hw, int return_xyxy, void* out_boxes, float* out_scores, int32_t* out_cls,
+                       int32_t* out_count, void* ws, size_t ws_bytes, void* stream) {
+  MGD_REQUIRE(cand_boxes && cand_scores && cand_cls && cand_count && image_hw && out_boxes && out_scores && out_cls &&
+                  out_count && ws,
+              "wbf: null pointer");
+  MGD_REQUIRE(max_boxes >= 1 && max_boxes <= 1024, "wbf: max_boxes=%d must be in [1,1024]", max_boxes);
+  MGD_REQUIRE(cap >= 1 && cap <= 16384, "wbf: cap=%d must be in [1,16384]", cap);
+  if (ws_bytes < (size_t)B * cap * 64) return mgd_set_error(MGD_ENOSPC, "wbf: workspace too small");
+  NmsArgs a;
+  a.boxes = cand_boxes; a.scores = cand_scores; a.cls = cand_cls; a.count = cand_count;
+  a.B = B; a.cap = cap; a.method = 0; a.max_boxes = max_boxes; a.return_xyxy = return_xyxy; a.thr = iou_threshold;
+  a.image_hw = image_hw; a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_cls = out_cls;
+  a.out_count = out_count; a.sorted = (float*)ws;
+  int np2 = 1;
+  while (np2 < cap) np2 <<= 1;
+  a.npow2 = np2;
+  size_t lds = (size_t)np2 * 8 + (size_t)(np2 / 32 + 1) * 4;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)wbf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(wbf_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, a);
+  MGD_CHECK_LAUNCH("wbf");
   return MGD_OK;
 }

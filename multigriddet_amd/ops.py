@@ -453,20 +453,28 @@ def decode(cfg, y_pred, image_hw):
     return boxes, scores, cls, count
 
 
-NMS_METHODS = {"standard": 0, "cluster": 0, "iou": 0, "diou": 1}
+NMS_METHODS = {"standard": 0, "cluster": 0, "iou": 0, "diou": 1, "soft": 2}
 
 
 def nms(boxes, scores, cls, count, image_hw, method="diou", threshold=0.5, max_boxes=100, return_xyxy=True):
+    """method: 'standard' / 'cluster' (IoU), 'diou', 'soft' (SoftNMS sigma 0.5, score threshold 1e-3), or 'wbf'
+    (Weighted Boxes Fusion with iou_thr = threshold).  Batched: one block per image."""
     lib = L.load()
     B, cap = scores.shape
     dev = boxes.device
-    need = lib.mgd_nms_workspace_size(B, cap)
+    wbf = method == "wbf"
+    need = lib.mgd_wbf_workspace_size(B, cap) if wbf else lib.mgd_nms_workspace_size(B, cap)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     ob = torch.zeros(B, max_boxes, 4, dtype=torch.int32 if return_xyxy else torch.float32, device=dev)
     osc = torch.zeros(B, max_boxes, dtype=torch.float32, device=dev)
     ocl = torch.zeros(B, max_boxes, dtype=torch.int32, device=dev)
     ocn = torch.zeros(B, dtype=torch.int32, device=dev)
-    L.check(lib.mgd_nms(L.ptr(boxes), L.ptr(scores), L.ptr(cls), L.ptr(count), B, cap, NMS_METHODS[method],
-                        C.c_float(threshold), max_boxes, L.ptr(image_hw), int(return_xyxy), L.ptr(ob), L.ptr(osc),
-                        L.ptr(ocl), L.ptr(ocn), L.ptr(ws), C.c_size_t(need), L.stream_ptr()), "nms")
+    if wbf:
+        L.check(lib.mgd_wbf(L.ptr(boxes), L.ptr(scores), L.ptr(cls), L.ptr(count), B, cap, C.c_float(threshold),
+                            max_boxes, L.ptr(image_hw), int(return_xyxy), L.ptr(ob), L.ptr(osc), L.ptr(ocl), L.ptr(ocn),
+                            L.ptr(ws), C.c_size_t(need), L.stream_ptr()), "wbf")
+    else:
+        L.check(lib.mgd_nms(L.ptr(boxes), L.ptr(scores), L.ptr(cls), L.ptr(count), B, cap, NMS_METHODS[method],
+                            C.c_float(threshold), max_boxes, L.ptr(image_hw), int(return_xyxy), L.ptr(ob), L.ptr(osc),
+                            L.ptr(ocl), L.ptr(ocn), L.ptr(ws), C.c_size_t(need), L.stream_ptr()), "nms")
     return ob, osc, ocl, ocn

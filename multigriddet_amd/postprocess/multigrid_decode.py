@@ -6,9 +6,9 @@ nms_method, use_wbf, return_xyxy) -> (boxes int32 (N,4) xyxy, classes int32 (N,)
 (reference multigriddet/postprocess/multigrid_decode.py:25-30, 347-395); empty results are three
 empty arrays (:274).  `postprocess_batch` is the batched device entry the inference/eval loops use
 (no per-image device->host copy before NMS, unlike evaluator.py:257).
-Differences, stated: nms_method 'soft' and use_wbf are host-side algorithms in the reference and are not
-on the device path (NotImplementedError); an unknown nms_method raises NotImplementedError exactly as
-the reference's abstract NMS does (multigrid_decode.py:297).
+nms_method 'diou' / 'cluster' / 'soft' and use_wbf=True all run on the device (mgd_nms methods 1 / 0 / 2, mgd_wbf);
+any other nms_method raises NotImplementedError exactly as the reference's abstract NMS does
+(multigrid_decode.py:297).
 """
 from typing import List, Sequence, Tuple
 
@@ -34,12 +34,13 @@ class MultiGridDecoder:
         return torch.from_numpy(np.ascontiguousarray(t, np.float32)).cuda()
 
     def postprocess_batch(self, outputs: Sequence, image_shapes, max_boxes=100, confidence=0.1, nms_threshold=0.5,
-                          nms_method="diou", return_xyxy=True):
+                          nms_method="diou", return_xyxy=True, use_wbf=False):
         """outputs: L tensors [B,g,g,F]; image_shapes: [B,2] (h,w).  Returns device tensors
         (boxes [B,max_boxes,4], scores [B,max_boxes], classes [B,max_boxes], count [B])."""
         if len(outputs) != self.num_layers:
             raise ValueError(f"Expected {self.num_layers} predictions, got {len(outputs)}")
-        if nms_method not in ops.NMS_METHODS:
+        if not use_wbf and (nms_method not in ops.NMS_METHODS or nms_method in ("standard", "iou")):
+            # the reference maps only 'diou' / 'soft' / 'cluster'; anything else reaches the abstract NMS.apply_nms
             raise NotImplementedError("Subclasses must implement apply_nms method")
         outs = [self._dev(o) for o in outputs]
         B = outs[0].shape[0]
@@ -48,20 +49,16 @@ class MultiGridDecoder:
         cfg = ops.make_decode_cfg(self.anchors, self.num_classes, self.input_shape, B, grids, confidence,
                                   use_softmax=self.use_softmax, rescore=self.rescore_confidence)
         b, s, c, n = ops.decode(cfg, outs, ihw)
-        return ops.nms(b, s, c, n, ihw, method=nms_method, threshold=nms_threshold, max_boxes=max_boxes,
-                       return_xyxy=return_xyxy)
+        return ops.nms(b, s, c, n, ihw, method="wbf" if use_wbf else nms_method, threshold=nms_threshold,
+                       max_boxes=max_boxes, return_xyxy=return_xyxy)
 
     def postprocess(self, multigriddet_outputs, image_shape, model_image_size, max_boxes: int = 100,
                     confidence: float = 0.1, nms_threshold: float = 0.5, use_iol: bool = True,
                     nms_method: str = "diou", use_wbf: bool = False, return_xyxy: bool = True):
-        if use_wbf:
-            raise NotImplementedError("WeightedBoxesFusion is not on the gfx950 path")
-        if nms_method == "soft":
-            raise NotImplementedError("SoftNMS is not on the gfx950 path")
         if tuple(model_image_size) != tuple(self.input_shape):
             self.input_shape = tuple(model_image_size)
         ob, osc, ocl, ocn = self.postprocess_batch(multigriddet_outputs, [image_shape], max_boxes, confidence,
-                                                   nms_threshold, nms_method, return_xyxy)
+                                                   nms_threshold, nms_method, return_xyxy, use_wbf=use_wbf)
         k = int(ocn[0])
         if k == 0:
             return np.array([]), np.array([]), np.array([])

@@ -526,6 +526,104 @@ def test_nms_vs_reference_fixture(dev, method, key, thr):
     assert np.array_equal(ocl[0, :k].cpu().numpy(), g[f"{tag}_classes"].astype(np.int32))
 
 
+def _nms_fixture(dev, cls_mod=None):
+    g = np.load(os.path.join(GOLDEN, "nms.npz"))
+    n = len(g["boxes"])
+    boxes = torch.from_numpy(g["boxes"]).to(dev).view(1, n, 4).contiguous()
+    scores = torch.from_numpy(g["scores"]).to(dev).view(1, n).contiguous()
+    c = g["classes"].astype(np.int32)
+    if cls_mod:
+        c = c % cls_mod
+    cls = torch.from_numpy(c).to(dev).view(1, n).contiguous()
+    count = torch.tensor([n], dtype=torch.int32, device=dev)
+    ihw = torch.tensor([[608.0, 608.0]], device=dev)
+    return g, boxes, scores, cls, count, ihw
+
+
+def test_soft_nms_vs_reference_fixture(dev):
+    """SoftNMS (nms.py:234-317) against the reference's own output: same survivors in the same (original) order,
+    decayed scores to 1e-5 relative (device expf vs numpy's)."""
+    from multigriddet_amd import ops
+    g, boxes, scores, cls, count, ihw = _nms_fixture(dev)
+    ob, osc, ocl, ocn = ops.nms(boxes, scores, cls, count, ihw, method="soft", threshold=0.45, max_boxes=512,
+                                return_xyxy=False)
+    torch.cuda.synchronize()
+    k = int(ocn[0])
+    assert k == len(g["soft_45_boxes"])
+    assert np.array_equal(ob[0, :k].cpu().numpy(), g["soft_45_boxes"])
+    assert np.array_equal(ocl[0, :k].cpu().numpy(), g["soft_45_classes"].astype(np.int32))
+    np.testing.assert_allclose(osc[0, :k].cpu().numpy(), g["soft_45_scores"], rtol=1e-5, atol=1e-7)
+    # more survivors than max_boxes: the top max_boxes by decayed score (postprocess _filter_boxes)
+    ob2, osc2, ocl2, ocn2 = ops.nms(boxes, scores, cls, count, ihw, method="soft", threshold=0.45, max_boxes=50,
+                                    return_xyxy=False)
+    torch.cuda.synchronize()
+    assert int(ocn2[0]) == 50
+    top = np.argsort(g["soft_45_scores"])[::-1][:50]
+    np.testing.assert_allclose(osc2[0, :50].cpu().numpy(), g["soft_45_scores"][top], rtol=1e-5, atol=1e-7)
+    # batch of two identical images + an empty one
+    b3 = torch.cat([boxes, boxes, boxes]); s3 = torch.cat([scores, scores, scores]); c3 = torch.cat([cls, cls, cls])
+    n3 = torch.tensor([int(count[0]), 0, int(count[0])], dtype=torch.int32, device=dev)
+    i3 = torch.cat([ihw, ihw, ihw])
+    _, osc3, _, ocn3 = ops.nms(b3, s3, c3, n3, i3, method="soft", max_boxes=512, return_xyxy=False)
+    torch.cuda.synchronize()
+    assert ocn3.cpu().tolist() == [k, 0, k]
+    assert torch.equal(osc3[0], osc3[2])
+
+
+def test_wbf_vs_reference_fixture(dev):
+    """Weighted Boxes Fusion (wbf.py) against the reference's own output (float64 boxes -> 1e-4 px, same clusters,
+    classes and order)."""
+    from multigriddet_amd import ops
+    w = np.load(os.path.join(GOLDEN, "wbf.npz"))
+    _, boxes, scores, cls, count, ihw = _nms_fixture(dev, cls_mod=3)
+    assert np.array_equal(cls[0].cpu().numpy(), w["classes"].astype(np.int32))
+    ob, osc, ocl, ocn = ops.nms(boxes, scores, cls, count, ihw, method="wbf", threshold=0.5, max_boxes=512,
+                                return_xyxy=False)
+    torch.cuda.synchronize()
+    k = int(ocn[0])
+    rb, rc, rs = w["out_boxes"][0], w["out_classes"][0], w["out_scores"][0]
+    assert k == len(rb)
+    assert np.array_equal(ocl[0, :k].cpu().numpy(), rc.astype(np.int32))
+    np.testing.assert_allclose(ob[0, :k].cpu().numpy(), rb, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(osc[0, :k].cpu().numpy(), rs, rtol=1e-6)
+    # integer boxes: rounded from the float64 cluster boxes like _convert_to_xyxy
+    obi, _, _, _ = ops.nms(boxes, scores, cls, count, ihw, method="wbf", threshold=0.5, max_boxes=512)
+    torch.cuda.synchronize()
+    xy = rb.astype(np.float64).copy()
+    xy[:, 2] += xy[:, 0]; xy[:, 3] += xy[:, 1]
+    xy = np.floor(np.clip(xy, 0, 608) + 0.5).astype(np.int32)
+    assert np.array_equal(obi[0, :k].cpu().numpy(), xy)
+    # top max_boxes by fused score when there are more clusters
+    ob2, osc2, _, ocn2 = ops.nms(boxes, scores, cls, count, ihw, method="wbf", threshold=0.5, max_boxes=20,
+                                 return_xyxy=False)
+    torch.cuda.synchronize()
+    assert int(ocn2[0]) == 20
+    np.testing.assert_allclose(osc2[0, :20].cpu().numpy(), np.sort(rs)[::-1][:20], rtol=1e-6)
+
+
+def test_decoder_soft_and_wbf_end_to_end(dev):
+    """MultiGridDecoder.postprocess(nms_method='soft') and (use_wbf=True) against the oracle pipeline."""
+    from multigriddet_amd.postprocess import MultiGridDecoder
+    from oracle import decode as od
+    size = 416
+    rng = np.random.default_rng(5)
+    heads = [(2.0 * rng.standard_normal((1, s, s, 88))).astype(np.float32) for s in (13, 26, 52)]
+    for h in heads:
+        h[..., 4] -= 2.0                  # fewer candidates
+    dec = MultiGridDecoder(coco_anchors(), 80, (size, size))
+    gb, gc, gs = dec.postprocess(heads, (375, 500), (size, size), max_boxes=100, confidence=0.3, nms_method="soft")
+    rb, rc, rs = od.postprocess(heads, coco_anchors(), 80, (size, size), (375, 500), (size, size), max_boxes=100,
+                                confidence=0.3, nms_method="soft")
+    assert len(gb) == len(rb) > 0
+    # both sides pick the top-100 decayed scores; compare as score-sorted sets
+    o1, o2 = np.argsort(-gs, kind="stable"), np.argsort(-rs, kind="stable")
+    np.testing.assert_allclose(gs[o1], rs[o2], rtol=2e-4)
+    assert (np.abs(gb[o1] - rb[o2]).max(axis=1) <= 1).mean() > 0.97
+    wb, wc, ws = dec.postprocess(heads, (375, 500), (size, size), max_boxes=100, confidence=0.3, nms_threshold=0.5,
+                                 use_wbf=True)
+    assert len(wb) > 0 and wb.dtype == np.int32 and len(wb) == len(wc) == len(ws) <= 100
+
+
 def test_decode_nms_batched_matches_single(dev):
     """Batch of 4 images with different original shapes == four single-image runs; empty image -> 0 boxes."""
     from multigriddet_amd import ops
