@@ -270,6 +270,23 @@ int mgd_wbf(const float* cand_boxes, const float* cand_scores, const int32_t* ca
             int32_t* out_count, void* ws, size_t ws_bytes, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Evaluation (mAP) hot spot: multigriddet/evaluation/metrics.py:28-71 (calculate_iou_matrix) and :73-219
+ * (match_predictions_to_gt / match_predictions_to_gt_cached).  float64 like the reference.
+ * mode 0: boxes are xyxy (the cached-IoU path); mode 1: the un-cached path's BoxUtils.box_iou
+ * (utils/boxes.py:16-57), which reads the same four numbers as (cx, cy, w, h) - the reference's per-scale
+ * metrics always go that way, so it is reproduced.
+ * mgd_eval_match: predictions are grouped by (image, class); group g owns predictions
+ * [group_pred_start[g], group_pred_start[g+1]) in DESCENDING score order and ground truths
+ * [group_gt_start[g], group_gt_start[g+1]).  For each of the num_thresholds (<= 16) IoU thresholds a prediction
+ * takes the unmatched ground truth of its group with the highest IoU (first maximum, IoU > 0) and is a true
+ * positive if that IoU >= threshold: tp[t][p] in {0,1}, tp is [num_thresholds][num_preds] bytes. */
+int mgd_iou_matrix(const double* boxes1 /*[n][4]*/, const double* boxes2 /*[m][4]*/, double* out /*[n][m]*/, int n, int m,
+                   int mode, void* stream);
+int mgd_eval_match(const double* pred_boxes, const int32_t* group_pred_start, const double* gt_boxes,
+                   const int32_t* group_gt_start, int num_groups, int max_group_gts, const double* thresholds,
+                   int num_thresholds, int mode, uint8_t* tp, long long num_preds, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
  * On-device batch augmentation (multigriddet/data/generators.py:561-1009 Mosaic, :1164-1282
  * GridMask, :1012-1161 MixUp).  Random draws are made on the host by the caller (so that the
  * oracle can consume the same draws) and passed in as small parameter arrays.

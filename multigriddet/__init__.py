@@ -6,7 +6,7 @@ import sys
 import multigriddet_amd as _impl
 
 __version__ = _impl.__version__
-for _sub in ("models", "losses", "data", "postprocess", "config", "trainers", "utils", "inference"):
+for _sub in ("models", "losses", "data", "postprocess", "config", "trainers", "utils", "inference", "evaluation"):
     _m = importlib.import_module(f"multigriddet_amd.{_sub}")
     sys.modules[f"{__name__}.{_sub}"] = _m
     globals()[_sub] = _m
