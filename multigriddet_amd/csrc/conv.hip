@@ -281,6 +281,10 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -641,7 +645,8 @@ struct GemmEpilogue {
   float bnp[4][8];
   bool bnred, addpre;
 
-  __device__ __forceinline__ void prefetch(const GemmArgs& a, const long long* row_dst, int co0, int tid) {
+  __device__ __forceinline__ void prefetch(const GemmArgs& a, const long long* row_dst, int co0, int tid,
+                                           bool sync = true) {
     bnred = a.bn_y != nullptr && !a.dst_f32;
     addpre = a.addend != nullptr && !a.dst_f32;
     if (bnred) {
@@ -656,7 +661,7 @@ struct GemmEpilogue {
       }
     }
     if (bnred || addpre) {
-      __syncthreads();
+      if (sync) __syncthreads();
 #pragma unroll
       for (int it = 0; it < EPC; ++it) {
         const int q = tid + it * NTHR;
@@ -947,6 +952,197 @@ __global__ __launch_bounds__(256) void conv_gemm4_kernel(GemmArgs a) {
   }
   __syncthreads();
   epi.run(a, acc, smem, row_dst, co0, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// v5: producer / consumer form of the gather-GEMM.  The v2 K-loop is bound by LDS-DMA issue + landing latency and
+// the block barrier per K-step (MGD_DBG=2 stamps: a wave spends 24 % of a K-step issuing its 8 LDS-DMA pieces,
+// 42 % waiting for the stage, 10 % in the barrier, 24 % on fragment reads + MFMA).  Here a block is 8 waves:
+// waves 0-3 only load (each its quarter of every stage, 2 stages kept in flight behind the one being published),
+// waves 4-7 only compute (64x64 wave tiles as in v2).  Stages live in an NS-deep LDS ring and are handed over
+// through two LDS counters per slot - full[slot] (+1 per loader wave once its pieces have landed) and free[slot]
+// (+1 per consumer wave once its fragment reads are done) - instead of s_barrier, so neither side ever waits
+// for the other's instruction stream, only for data.  One block per CU.  Out-of-image taps come from a zero page.
+// hand-off counters: prod[w] = stages loader wave w has landed, cons[w] = stages consumer wave w has finished
+// reading; each is written by exactly one wave (plain ds_write) and all four are read with one ds_read_b128.
+__device__ __forceinline__ void lds_flag_set(unsigned addr, int v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ int lds_flag_min4(unsigned addr) {
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  i32x4 r;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr) : "memory");
+  return __builtin_amdgcn_readfirstlane(min(min(r[0], r[1]), min(r[2], r[3])));
+}
+// wave-uniform bounded spin until min(counter[0..3]) > need (a lost hand-off must not hang the GPU: after ~1M polls
+// the wave gives up and the launch finishes with wrong numbers, which the parity tests catch)
+__device__ __forceinline__ int lds_flag_wait_gt(unsigned addr, int need) {
+  int v = lds_flag_min4(addr);
+  int spins = 0;
+  while (v <= need) {
+    if (spins > 8) __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 20)) break;
+    v = lds_flag_min4(addr);
+  }
+  return v;
+}
+
+template <int WC, int WP, int MT, int NT, int NS>
+__global__ __launch_bounds__(512) void conv_gemm5_kernel(GemmArgs a) {
+  using Epi = GemmEpilogue<WC, WP, MT, NT>;
+  constexpr int BNC = WC * MT * 16;
+  constexpr int BMP = WP * NT * 16;
+  static_assert(WC * WP == 4 && BMP == 128, "4 consumer waves, 128-pixel tile");
+  constexpr int WCH = BNC / 32;                 // weight pieces per loader wave per stage
+  constexpr int XCH = BMP / 32;                 // pixel pieces per loader wave per stage
+  constexpr int LPS = WCH + XCH;
+  constexpr int LAG = 2;                        // stages kept in flight behind the one being published
+  constexpr int STAGE = (BNC + BMP) * ROWB;
+  constexpr int RING = NS * STAGE;
+  constexpr int EPI_MAX = BMP * (BNC * 4 + 16);
+  constexpr int AUX = RING > EPI_MAX ? RING : EPI_MAX;
+  static_assert(NS >= LAG + 2 && NS <= 8, "ring depth");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  long long* row_dst = (long long*)(smem + AUX);
+  const unsigned flags = lds_addr(smem + AUX + BMP * 8);      // prod[4] then cons[4]
+
+  const int tid = threadIdx.x;
+  const bool loader = tid < 256;
+  const int ltid = tid & 255, lane = tid & 63, wave = ltid >> 6;
+  const int L = xcd_remap(blockIdx.x, a.nblk);
+  const int tc = L % a.tilesC, tp = L / a.tilesC;
+  const int co0 = tc * BNC;
+  const int pix0 = tp * BMP;
+  const int nk = a.K_pad / BK;
+
+  if (tid < BMP) {
+    int m = pix0 + tid;
+    long long off = -1;
+    if (m < a.M) {
+      int hw = a.Hg * a.Wg;
+      int n = m / hw, rem = m - n * hw;
+      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+      int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
+      off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
+    }
+    row_dst[tid] = off;
+  }
+  if (tid >= 256 && tid < 256 + 8) *(int*)(smem + AUX + BMP * 8 + (tid - 256) * 4) = 0;
+  __syncthreads();
+
+  if (loader) {
+    // thread -> LDS slot (ltid & 7) of rows (ltid >> 3) + 32 i ; source chunk kc = slot ^ (row & 7)
+    const int rlo = ltid >> 3;
+    const int kc = (ltid & 7) ^ (rlo & 7);
+    unsigned xoff[XCH], vmask[XCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      int m = pix0 + rlo + 32 * i;
+      xoff[i] = 0;
+      vmask[i] = 0;
+      if (m < a.M) {
+        int hw = a.Hg * a.Wg;
+        int n = m / hw, rem = m - n * hw;
+        int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+        int hs = ig * a.in_stride, ws = jg * a.in_stride;
+        xoff[i] = (unsigned)(((((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci) * 2);
+        for (int t = 0; t < a.ntaps; ++t) {
+          int dh = (int)((a.tapcode >> (4 * t)) & 3) - 1, dw = (int)((a.tapcode >> (4 * t + 2)) & 3) - 1;
+          if ((unsigned)(hs + dh) < (unsigned)a.Hs && (unsigned)(ws + dw) < (unsigned)a.Ws) vmask[i] |= 1u << t;
+        }
+      }
+    }
+    int tap = (kc * 8) / a.Ci;
+    int cch = (kc * 8) - tap * a.Ci;
+    unsigned woff[WCH];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) woff[i] = (unsigned)(((long long)(co0 + rlo + 32 * i) * a.K_pad + kc * 8) * 2);
+    const char* xbase = (const char*)a.src;
+    const char* wbase = (const char*)a.wpk;
+    const void* zero = (const void*)g_zero_page;
+
+    int slot = 0;                     // ring slot of the stage being issued
+    int freed = 0;                    // cached min(cons[]): stages every consumer has finished with
+    int published = 0;                // stages this wave has published
+    for (int s = 0; s < nk; ++s) {
+      if (s >= freed + NS) {
+        // ring full: nothing to issue.  Hand over everything but the youngest stage (waiting for that one would
+        // put its whole landing latency in front of the next issue), then wait for a slot.
+        if (published < s - 1) {
+          wait_vmcnt<LPS>();
+          published = s - 1;
+          if (lane == 0) lds_flag_set(flags + wave * 4, published);
+        }
+        freed = lds_flag_wait_gt(flags + 16, s - NS);
+      }
+      unsigned char* wb = smem + slot * STAGE + wave * 1024;
+      unsigned char* xb = wb + BNC * ROWB;
+#pragma unroll
+      for (int i = 0; i < WCH; ++i) glds16(wbase + woff[i] + (unsigned)s * (BK * 2), wb + i * (32 * ROWB));
+      int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
+      int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
+      int toff = ((dh * a.Ws + dw) * a.Ci + cch) * 2;
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        bool v = (vmask[i] >> tap) & 1u;
+        const void* g = v ? (const void*)(xbase + (long long)xoff[i] + toff) : zero;
+        glds16(g, xb + i * (32 * ROWB));
+      }
+      cch += BK;
+      while (cch >= a.Ci) { cch -= a.Ci; ++tap; }
+      if (++slot == NS) slot = 0;
+      if (s + 1 - LAG > published) {       // streaming: stage s - LAG has landed once at most LAG stages are in flight
+        wait_vmcnt<LAG * LPS>();
+        published = s + 1 - LAG;
+        if (lane == 0) lds_flag_set(flags + wave * 4, published);
+      }
+    }
+    wait_vmcnt<0>();
+    if (lane == 0) lds_flag_set(flags + wave * 4, nk);
+    __syncthreads();
+    return;
+  }
+
+  // ---------------------------------------------------------------- consumers
+  const int wc = wave / WP, wp = wave % WP;
+  Epi epi;
+  epi.prefetch(a, row_dst, co0, ltid, false);
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  int wro[MT], xro[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) wro[m] = lds_off((wc * MT + m) * 16 + fr, fq);
+#pragma unroll
+  for (int n = 0; n < NT; ++n) xro[n] = BNC * ROWB + lds_off((wp * NT + n) * 16 + fr, fq);
+  int slot = 0;
+  int avail = 0;                      // cached min(prod[]): stages every loader has landed
+  for (int s = 0; s < nk; ++s) {
+    if (s >= avail) avail = lds_flag_wait_gt(flags, s);
+    const unsigned char* sb = smem + slot * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 wf[MT], xf[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(sb + (wro[m] ^ (kk << 6)));
+#pragma unroll
+      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + (xro[n] ^ (kk << 6)));
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my fragment reads of this slot are done
+    if (lane == 0) lds_flag_set(flags + 16 + wave * 4, s + 1);
+    if (++slot == NS) slot = 0;
+  }
+  __syncthreads();
+  epi.run(a, acc, smem, row_dst, co0, ltid);
 }
 
 template <int WC, int WP, int MT, int NT, int NST>
@@ -1388,9 +1584,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
-}
 // ds_read_b64_tr_b16 the compiler does not see (no automatic waits: pair with wait_lgkm_dyn + touch)
 template <int OFF>
 __device__ __forceinline__ void tr_read_asm(s16x4& dst, unsigned addr) {
@@ -2032,6 +2225,8 @@ unsigned long long make_tapcode(int ntaps, const int32_t* dh, const int32_t* dw,
   return code;
 }
 
+__device__ unsigned long long g_stamps[8];
+
 template <int WC, int WP, int MT, int NT>
 int launch_gemm(GemmArgs& a, hipStream_t st) {
   constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
@@ -2090,6 +2285,24 @@ int launch_gemm4(GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
+template <int WC, int WP, int MT, int NT, int NS>
+int launch_gemm5(GemmArgs& a, hipStream_t st) {
+  constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
+  a.tilesC = a.Co_pad / BNC;
+  a.nblk = a.tilesC * cdiv(a.M, BMP);
+  size_t ring = (size_t)NS * (BNC + BMP) * ROWB;
+  size_t epi = (size_t)BMP * (BNC * 4 + 16);
+  size_t lds = (ring > epi ? ring : epi) + (size_t)BMP * 8 + 64;
+  auto k = conv_gemm5_kernel<WC, WP, MT, NT, NS>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(512), lds, st, a);
+  return 0;
+}
+
 template <int WC, int WP, int MT, int NT, int NST>
 int launch_gemm3(GemmArgs& a, hipStream_t st) {
   constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
@@ -2109,7 +2322,6 @@ int launch_gemm3(GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
-__device__ unsigned long long g_stamps[8];
 int launch_gemm2_stamped(GemmArgs& a, hipStream_t st) {
   constexpr int BNC = 128, BMP = 128, NST = 2;
   a.tilesC = a.Co_pad / BNC;
@@ -2213,7 +2425,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     variant = e ? atoi(e) : 3;
   }
   const int nk = d->K_pad / BK;
-  MGD_REQUIRE(!d->bn_y || variant == 3 || variant == 7, "conv: the fused BN-backward reduction needs the default gemm variant (MGD_GEMM=3)");
+  MGD_REQUIRE(!d->bn_y || variant == 3 || variant == 7 || variant == 8, "conv: the fused BN-backward reduction needs the default gemm variant (MGD_GEMM=3)");
   // row-shift form: 3x3 in the standard tap order, stride 1, same-size maps, whole 64-channel chunks
   bool std9 = d->ntaps == 9 && d->in_stride == 1 && d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 &&
               d->Hs == d->Hg && d->Ws == d->Wg && d->Hd == d->Hg && d->Wd == d->Wg && d->Ci % BK == 0 &&
@@ -2221,6 +2433,17 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   for (int t = 0; t < 9 && std9; ++t) std9 = d->dh[t] == t / 3 - 1 && d->dw[t] == t % 3 - 1;
   static int rowshift = -1;
   if (rowshift < 0) { const char* e = getenv("MGD_ROWSHIFT"); rowshift = e ? atoi(e) : 0; }   // opt-in: measured equal to v2 (the K-loop is not bound by LDS-DMA bytes)
+  // producer/consumer form: wins when the launch has at most one 128x128 tile per CU (the small-map layers and
+  // their data gradients: 1.2-1.6x), loses to two barrier-synchronous blocks per CU when the chip is over-subscribed
+  static int pc = -1;
+  if (pc < 0) { const char* e = getenv("MGD_PRODCONS"); pc = e ? atoi(e) : 1; }
+  const long long nblk128 = (long long)(d->Co_pad / 128) * cdiv(a.M, 128);
+  if (d->Co_pad % 128 == 0 && d->K_pad / BK >= 4 && !d->dst_f32 &&
+      (variant == 8 || (variant == 3 && pc && nblk128 <= 256))) {
+    launch_gemm5<2, 2, 4, 4, 4>(a, st);
+    MGD_CHECK_LAUNCH("conv_gather_gemm(producer/consumer)");
+    return MGD_OK;
+  }
   if (variant == 3 && rowshift && std9) {
     if (d->Co_pad % 128 == 0) launch_gemm4<2, 2, 4, 4>(a, st);
     else if (d->Co_pad % 64 == 0) launch_gemm4<1, 4, 4, 2>(a, st);
