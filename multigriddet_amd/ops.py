@@ -203,13 +203,26 @@ _WGRAD_BLOCKS = int(_os.environ.get("MGD_WGRAD_BLOCKS", "512"))
 
 
 def wgrad_splits(P, co, ci, T, target_blocks=None):
-    # measured (tools/bench_conv.py): the fp32-atomic epilogue costs as much as ~25 % of a block, so fewer,
-    # longer blocks win until the chip is under-filled: ~2 blocks/CU for 3x3, ~1 block/CU for 1x1.
-    target_blocks = target_blocks or (_WGRAD_BLOCKS if T > 1 else _WGRAD_BLOCKS // 2)
+    """Split-K factor of the per-tap weight-gradient kernel.  Cost model fitted to tools/bench_wgrad_splits.py (it
+    reproduces the measured optimum on every layer of the graph): blocks = tiles * splits run two per CU, so
+    ceil(blocks / 512) rounds of K-steps at 1.63 us each, plus the fp32-atomic epilogue, which is bound by the
+    memory-side atomic rate (64 KB per block at 1.3 TB/s = 0.05 us per block, not overlapped)."""
     bco = 128 if co > 64 else (64 if co > 32 else 32)
     bci = 128 if ci > 64 else (64 if ci > 32 else 32)
-    base = -(-co // bco) * -(-ci // bci) * T
-    return max(1, min(int(target_blocks / base + 0.5), -(-P // 256)))
+    tiles = -(-co // bco) * -(-ci // bci) * T
+    if target_blocks or T == 1:        # 1x1: ~1 block per CU, measured (short blocks, the epilogue dominates)
+        target_blocks = target_blocks or _WGRAD_BLOCKS // 2
+        return max(1, min(int(target_blocks / tiles + 0.5), -(-P // 256)))
+    slots = _WGRAD_BLOCKS
+    atom = 0.05 * (bco * bci) / (128.0 * 128.0)
+    best, best_cost = 1, None
+    for sp in range(1, max(1, min(256, P // 256)) + 1):
+        blocks = tiles * sp
+        steps = -(-(-(-P // sp)) // 64)
+        cost = -(-blocks // slots) * steps * 1.63 + blocks * atom
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = sp, cost
+    return best
 
 
 def conv_wgrad(x, dy, dw, k, s, splits=None):
