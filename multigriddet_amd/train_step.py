@@ -38,6 +38,10 @@ class TrainStep:
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
         self.dp = GradBuckets(net.grads, [cv.off_w for cv in net.layers], world_size, bucket_mb, self.comm_stream,
                               producer_streams=(net.wg_stream,))
+        # hipGraph replay of the whole step (single process, Adam/AdamW): see enable_graph()
+        self.use_graph = False
+        self._graphs = {}
+        self._hyper = torch.zeros(2, dtype=torch.float32, device=dev)
 
     # ------------------------------------------------------------------ helpers
     def _grids(self, H, W):
@@ -54,9 +58,63 @@ class TrainStep:
         return self._loss[key], self._douts[key]
 
     # ------------------------------------------------------------------ the step
+    def enable_graph(self, on=True):
+        """Replay the step from a captured hipGraph (torch.cuda.CUDAGraph over both streams) instead of launching
+        its ~450 kernels from Python: the backward pass is otherwise launch-bound on the host (0.85 ms of gaps on
+        the compute stream).  Single-process Adam/AdamW only; the first two steps of a new input shape run
+        eagerly (they size arenas and set kernel attributes), the third is captured.  Adam's bias-corrected step
+        size lives in device memory (mgd_adam_step_dev) and is refreshed before every replay."""
+        self.use_graph = bool(on)
+
+    def _graphable(self, boxes):
+        return self.use_graph and self.world == 1 and boxes is not None and self.optimizer in ("adam", "adamw")
+
+    def _adam_hyper(self):
+        b1, b2 = self.opt_kwargs.get("beta_1", 0.9), self.opt_kwargs.get("beta_2", 0.999)
+        t = self.step_count
+        lr_t = self.lr * (1.0 - b2 ** t) ** 0.5 / (1.0 - b1 ** t)
+        wd = self.opt_kwargs.get("weight_decay", 5e-4) if self.optimizer == "adamw" else 0.0
+        return lr_t, self.lr * wd
+
+    def _step_graph(self, images, boxes):
+        net = self.net
+        key = (tuple(images.shape), tuple(boxes.shape), net.freeze_backbone, net.freeze_all_but_pred, net.freeze_bn)
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._graphs[key] = {"eager": 0, "graph": None}
+        if st["graph"] is None and st["eager"] < 2:
+            st["eager"] += 1
+            return self._step_eager(images, boxes, None)
+        self.step_count += 1
+        lr_t, lr_wd = self._adam_hyper()
+        self._hyper[0:1].fill_(lr_t)
+        self._hyper[1:2].fill_(lr_wd)
+        if st["graph"] is None:
+            st["images"], st["boxes"] = images.clone(), boxes.clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["comp"] = self._step_body(st["images"], st["boxes"], None, dev_hyper=True)
+            st["graph"] = g
+        if images.data_ptr() != st["images"].data_ptr():
+            st["images"].copy_(images)
+        if boxes.data_ptr() != st["boxes"].data_ptr():
+            st["boxes"].copy_(boxes)
+        st["graph"].replay()
+        return st["comp"]
+
     def step(self, images, boxes=None, y_true=None):
         """images fp32 CUDA [B,H,W,3] in [0,1]; boxes fp32 CUDA [B,M,5] (x1,y1,x2,y2,cls) or ready y_true.
         Returns the device tensor of 8 loss components (index 7 = total)."""
+        if y_true is None and self._graphable(boxes):
+            return self._step_graph(images, boxes)
+        return self._step_eager(images, boxes, y_true)
+
+    def _step_eager(self, images, boxes, y_true):
+        self.step_count += 1
+        return self._step_body(images, boxes, y_true, dev_hyper=False)
+
+    def _step_body(self, images, boxes, y_true, dev_hyper):
         net = self.net
         B, H, W, _ = images.shape
         if y_true is None:
@@ -73,12 +131,12 @@ class TrainStep:
             self.dp.finish()      # makes the compute stream wait for the collectives
         else:
             net.backward(douts)
-        self.apply_optimizer()
+        self.apply_optimizer(dev_hyper=dev_hyper)
         return comp
 
-    def apply_optimizer(self):
+    def apply_optimizer(self, dev_hyper=False):
+        """step_count has been advanced by the caller."""
         net = self.net
-        self.step_count += 1
         gs = 1.0 / self.world
         if net.freeze_all_but_pred:
             ranges = [(cv.off_w, cv.end) for cv in net.layers if cv.role == "pred"]
@@ -87,10 +145,13 @@ class TrainStep:
         for b, e in ranges:
             p, g, m = net.params[b:e], net.grads[b:e], self.m[b:e]
             if self.optimizer in ("adam", "adamw"):
-                ops.adam_step(p, g, m, self.v[b:e], self.lr, self.step_count,
-                              b1=self.opt_kwargs.get("beta_1", 0.9), b2=self.opt_kwargs.get("beta_2", 0.999),
-                              eps=self.opt_kwargs.get("epsilon", 1e-7), grad_scale=gs,
-                              weight_decay=self.opt_kwargs.get("weight_decay", 5e-4) if self.optimizer == "adamw" else 0.0)
+                b1, b2 = self.opt_kwargs.get("beta_1", 0.9), self.opt_kwargs.get("beta_2", 0.999)
+                eps = self.opt_kwargs.get("epsilon", 1e-7)
+                if dev_hyper:
+                    ops.adam_step_dev(p, g, m, self.v[b:e], self._hyper, b1=b1, b2=b2, eps=eps, grad_scale=gs)
+                else:
+                    ops.adam_step(p, g, m, self.v[b:e], self.lr, self.step_count, b1=b1, b2=b2, eps=eps, grad_scale=gs,
+                                  weight_decay=self.opt_kwargs.get("weight_decay", 5e-4) if self.optimizer == "adamw" else 0.0)
             else:
                 ops.sgd_step(p, g, m, self.lr, momentum=self.opt_kwargs.get("momentum", 0.937),
                              nesterov=self.opt_kwargs.get("nesterov", True), grad_scale=gs)

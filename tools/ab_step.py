@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of engine switches on the benchmark train step (one process, same device, median of rounds).
-usage: python tools/ab_step.py attr=v1,v2 [attr2=...]   e.g.  fuse_bn_reduce=0,1 overlap_wgrad=0,1"""
+usage: python tools/ab_step.py attr=v1,v2 [attr2=...]   e.g.  fuse_bn_reduce=0,1 overlap_wgrad=0,1 ts.use_graph=0,1
+(plain names are attributes of the Network, ts.* of the TrainStep)"""
 import itertools, os, statistics, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +22,10 @@ res = {c: [] for c in combos}
 for rnd in range(4):
     for c in combos:
         for n, v in zip(names, c):
-            setattr(net, n, bool(v))
+            if n.startswith("ts."):
+                setattr(ts, n[3:], bool(v))
+            else:
+                setattr(net, n, bool(v))
         for _ in range(2):
             ts.step(img, bx)
         torch.cuda.synchronize()
