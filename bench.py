@@ -126,12 +126,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # rehearsal on a one-GPU box: MGD_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo for the exchange
+    # (RCCL refuses two ranks on one device); the data-parallel code path is otherwise the one the 8-GPU run takes
+    share = os.environ.get("MGD_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from multigriddet_amd import ops
     from multigriddet_amd.engine import Network
