@@ -955,40 +955,18 @@ __global__ __launch_bounds__(256) void conv_gemm4_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// v5: producer / consumer form of the gather-GEMM.  The v2 K-loop is bound by LDS-DMA issue + landing latency and
-// the block barrier per K-step (MGD_DBG=2 stamps: a wave spends 24 % of a K-step issuing its 8 LDS-DMA pieces,
-// 42 % waiting for the stage, 10 % in the barrier, 24 % on fragment reads + MFMA).  Here a block is 8 waves:
-// waves 0-3 only load (each its quarter of every stage, 2 stages kept in flight behind the one being published),
-// waves 4-7 only compute (64x64 wave tiles as in v2).  Stages live in an NS-deep LDS ring and are handed over
-// through two LDS counters per slot - full[slot] (+1 per loader wave once its pieces have landed) and free[slot]
-// (+1 per consumer wave once its fragment reads are done) - instead of s_barrier, so neither side ever waits
-// for the other's instruction stream, only for data.  One block per CU.  Out-of-image taps come from a zero page.
-// hand-off counters: prod[w] = stages loader wave w has landed, cons[w] = stages consumer wave w has finished
-// reading; each is written by exactly one wave (plain ds_write) and all four are read with one ds_read_b128.
-__device__ __forceinline__ void lds_flag_set(unsigned addr, int v) {
-  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ int lds_flag_min4(unsigned addr) {
-  typedef __attribute__((ext_vector_type(4))) int i32x4;
-  i32x4 r;
-  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr) : "memory");
-  return __builtin_amdgcn_readfirstlane(min(min(r[0], r[1]), min(r[2], r[3])));
-}
-// wave-uniform bounded spin until min(counter[0..3]) > need (a lost hand-off must not hang the GPU: after ~1M polls
-// the wave gives up and the launch finishes with wrong numbers, which the parity tests catch)
-__device__ __forceinline__ int lds_flag_wait_gt(unsigned addr, int need) {
-  int v = lds_flag_min4(addr);
-  int spins = 0;
-  while (v <= need) {
-    if (spins > 8) __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1 << 20)) break;
-    v = lds_flag_min4(addr);
-  }
-  return v;
-}
-
+// v6: producer / consumer form of the gather-GEMM.  The v2 K-loop is bound by LDS-DMA issue + landing latency and the
+// block barrier per K-step (MGD_DBG=2 stamps: a wave spends 24 % of a K-step issuing its 8 LDS-DMA pieces, 42 %
+// waiting for the stage, 10 % in the barrier, 24 % on fragment reads + MFMA).  Here a block is 8 waves: waves 0-3
+// only load (each its quarter of every stage), waves 4-7 only compute (64x64 wave tiles as in v2), with ONE
+// s_barrier per K-step as the hand-off over a 3-stage LDS ring: loader waves wait for stage s to land, everyone
+// meets at the barrier, then the loaders issue stage s+2 into the slot the consumers have just left while the
+// consumers compute stage s - a wave's LDS-DMA issue time (~840 ticks per stage) no longer sits in front of its
+// own MFMAs.  One block per CU; out-of-image taps come from a zero page.  (A first version handed stages over
+// through per-wave LDS counters instead of the barrier: each side then waited about as long for the other's
+// counter as it worked, and it lost to this form on every layer.)
 template <int WC, int WP, int MT, int NT, int NS>
-__global__ __launch_bounds__(512) void conv_gemm5_kernel(GemmArgs a) {
+__global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
   using Epi = GemmEpilogue<WC, WP, MT, NT>;
   constexpr int BNC = WC * MT * 16;
   constexpr int BMP = WP * NT * 16;
@@ -996,16 +974,14 @@ __global__ __launch_bounds__(512) void conv_gemm5_kernel(GemmArgs a) {
   constexpr int WCH = BNC / 32;                 // weight pieces per loader wave per stage
   constexpr int XCH = BMP / 32;                 // pixel pieces per loader wave per stage
   constexpr int LPS = WCH + XCH;
-  constexpr int LAG = 2;                        // stages kept in flight behind the one being published
   constexpr int STAGE = (BNC + BMP) * ROWB;
   constexpr int RING = NS * STAGE;
   constexpr int EPI_MAX = BMP * (BNC * 4 + 16);
   constexpr int AUX = RING > EPI_MAX ? RING : EPI_MAX;
-  static_assert(NS >= LAG + 2 && NS <= 8, "ring depth");
+  static_assert(NS == 3, "3-stage ring");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   long long* row_dst = (long long*)(smem + AUX);
-  const unsigned flags = lds_addr(smem + AUX + BMP * 8);      // prod[4] then cons[4]
 
   const int tid = threadIdx.x;
   const bool loader = tid < 256;
@@ -1028,7 +1004,6 @@ __global__ __launch_bounds__(512) void conv_gemm5_kernel(GemmArgs a) {
     }
     row_dst[tid] = off;
   }
-  if (tid >= 256 && tid < 256 + 8) *(int*)(smem + AUX + BMP * 8 + (tid - 256) * 4) = 0;
   __syncthreads();
 
   if (loader) {
@@ -1062,20 +1037,7 @@ __global__ __launch_bounds__(512) void conv_gemm5_kernel(GemmArgs a) {
     const char* wbase = (const char*)a.wpk;
     const void* zero = (const void*)g_zero_page;
 
-    int slot = 0;                     // ring slot of the stage being issued
-    int freed = 0;                    // cached min(cons[]): stages every consumer has finished with
-    int published = 0;                // stages this wave has published
-    for (int s = 0; s < nk; ++s) {
-      if (s >= freed + NS) {
-        // ring full: nothing to issue.  Hand over everything but the youngest stage (waiting for that one would
-        // put its whole landing latency in front of the next issue), then wait for a slot.
-        if (published < s - 1) {
-          wait_vmcnt<LPS>();
-          published = s - 1;
-          if (lane == 0) lds_flag_set(flags + wave * 4, published);
-        }
-        freed = lds_flag_wait_gt(flags + 16, s - NS);
-      }
+    auto issue = [&](int s, int slot) {
       unsigned char* wb = smem + slot * STAGE + wave * 1024;
       unsigned char* xb = wb + BNC * ROWB;
 #pragma unroll
@@ -1091,15 +1053,15 @@ __global__ __launch_bounds__(512) void conv_gemm5_kernel(GemmArgs a) {
       }
       cch += BK;
       while (cch >= a.Ci) { cch -= a.Ci; ++tap; }
-      if (++slot == NS) slot = 0;
-      if (s + 1 - LAG > published) {       // streaming: stage s - LAG has landed once at most LAG stages are in flight
-        wait_vmcnt<LAG * LPS>();
-        published = s + 1 - LAG;
-        if (lane == 0) lds_flag_set(flags + wave * 4, published);
-      }
+    };
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int islot = 2;
+    for (int s = 0; s < nk; ++s) {
+      if (s + 1 < nk) wait_vmcnt<LPS>(); else wait_vmcnt<0>();     // stage s has landed (s+1 may be in flight)
+      __builtin_amdgcn_s_barrier();                                // consumers: stage s is yours, stage s-1's slot is free
+      if (s + 2 < nk) { issue(s + 2, islot); if (++islot == NS) islot = 0; }
     }
-    wait_vmcnt<0>();
-    if (lane == 0) lds_flag_set(flags + wave * 4, nk);
     __syncthreads();
     return;
   }
@@ -1120,9 +1082,8 @@ __global__ __launch_bounds__(512) void conv_gemm5_kernel(GemmArgs a) {
 #pragma unroll
   for (int n = 0; n < NT; ++n) xro[n] = BNC * ROWB + lds_off((wp * NT + n) * 16 + fr, fq);
   int slot = 0;
-  int avail = 0;                      // cached min(prod[]): stages every loader has landed
   for (int s = 0; s < nk; ++s) {
-    if (s >= avail) avail = lds_flag_wait_gt(flags, s);
+    __builtin_amdgcn_s_barrier();
     const unsigned char* sb = smem + slot * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -1137,8 +1098,7 @@ __global__ __launch_bounds__(512) void conv_gemm5_kernel(GemmArgs a) {
         for (int n = 0; n < NT; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my fragment reads of this slot are done
-    if (lane == 0) lds_flag_set(flags + 16 + wave * 4, s + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my fragment reads of this slot are done before the next barrier
     if (++slot == NS) slot = 0;
   }
   __syncthreads();
@@ -2286,14 +2246,14 @@ int launch_gemm4(GemmArgs& a, hipStream_t st) {
 }
 
 template <int WC, int WP, int MT, int NT, int NS>
-int launch_gemm5(GemmArgs& a, hipStream_t st) {
+int launch_gemm6(GemmArgs& a, hipStream_t st) {
   constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
   a.tilesC = a.Co_pad / BNC;
   a.nblk = a.tilesC * cdiv(a.M, BMP);
   size_t ring = (size_t)NS * (BNC + BMP) * ROWB;
   size_t epi = (size_t)BMP * (BNC * 4 + 16);
   size_t lds = (ring > epi ? ring : epi) + (size_t)BMP * 8 + 64;
-  auto k = conv_gemm5_kernel<WC, WP, MT, NT, NS>;
+  auto k = conv_gemm6_kernel<WC, WP, MT, NT, NS>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2425,7 +2385,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     variant = e ? atoi(e) : 3;
   }
   const int nk = d->K_pad / BK;
-  MGD_REQUIRE(!d->bn_y || variant == 3 || variant == 7 || variant == 8, "conv: the fused BN-backward reduction needs the default gemm variant (MGD_GEMM=3)");
+  MGD_REQUIRE(!d->bn_y || variant == 3 || variant == 7 || variant == 9, "conv: the fused BN-backward reduction needs the default gemm variant (MGD_GEMM=3)");
   // row-shift form: 3x3 in the standard tap order, stride 1, same-size maps, whole 64-channel chunks
   bool std9 = d->ntaps == 9 && d->in_stride == 1 && d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 &&
               d->Hs == d->Hg && d->Ws == d->Wg && d->Hd == d->Hg && d->Wd == d->Wg && d->Ci % BK == 0 &&
@@ -2433,14 +2393,14 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   for (int t = 0; t < 9 && std9; ++t) std9 = d->dh[t] == t / 3 - 1 && d->dw[t] == t % 3 - 1;
   static int rowshift = -1;
   if (rowshift < 0) { const char* e = getenv("MGD_ROWSHIFT"); rowshift = e ? atoi(e) : 0; }   // opt-in: measured equal to v2 (the K-loop is not bound by LDS-DMA bytes)
-  // producer/consumer form: wins when the launch has at most one 128x128 tile per CU (the small-map layers and
-  // their data gradients: 1.2-1.6x), loses to two barrier-synchronous blocks per CU when the chip is over-subscribed
+  // producer/consumer form: wins when the launch has few tiles per CU or long K-loops (its single block per CU leaves
+  // prologue and epilogue exposed, which two barrier-synchronous blocks per CU hide on the short-K, many-tile layers)
   static int pc = -1;
   if (pc < 0) { const char* e = getenv("MGD_PRODCONS"); pc = e ? atoi(e) : 1; }
   const long long nblk128 = (long long)(d->Co_pad / 128) * cdiv(a.M, 128);
-  if (d->Co_pad % 128 == 0 && d->K_pad / BK >= 4 && !d->dst_f32 &&
-      (variant == 8 || (variant == 3 && pc && nblk128 <= 256))) {
-    launch_gemm5<2, 2, 4, 4, 4>(a, st);
+  if (d->Co_pad % 128 == 0 && nk >= 4 && !d->dst_f32 &&
+      (variant == 9 || (variant == 3 && pc && (nblk128 <= 256 || (nblk128 <= 768 && nk >= 32))))) {
+    launch_gemm6<2, 2, 4, 4, 3>(a, st);
     MGD_CHECK_LAUNCH("conv_gather_gemm(producer/consumer)");
     return MGD_OK;
   }

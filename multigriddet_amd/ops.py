@@ -30,9 +30,9 @@ def _launch_gemm(d, what):
     L.check(lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), what)
     e1.record()
     variant = "gemm128" if d.Co_pad % 128 == 0 else ("gemm64" if d.Co_pad % 64 == 0 else "gemm32")
-    if variant == "gemm128" and not d.dst_f32 and d.K_pad // 64 >= 4 and \
-            (d.Co_pad // 128) * -(-(d.N * d.Hg * d.Wg) // 128) <= 256:
-        variant = "gemm128pc"        # dispatched to the producer/consumer kernel (conv.hip: nblk128 <= 256)
+    nb, nk = (d.Co_pad // 128) * -(-(d.N * d.Hg * d.Wg) // 128), d.K_pad // 64
+    if variant == "gemm128" and not d.dst_f32 and nk >= 4 and (nb <= 256 or (nb <= 768 and nk >= 32)):
+        variant = "gemm128pc"        # dispatched to the producer/consumer kernel (same rule as conv.hip)
     PROFILE.append((e0, e1, 2.0 * d.N * d.Hg * d.Wg * d.ntaps * d.Ci * d.Co, variant, what))
 
 
