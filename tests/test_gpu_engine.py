@@ -230,3 +230,31 @@ def test_graph_replay_matches_eager_step():
     assert np.all(np.isfinite(b))
     np.testing.assert_allclose(b, a, rtol=2e-2)
     assert a[-1] < a[0]                      # it trains
+
+
+@pytest.mark.gpu
+def test_multiscale_steps_share_one_network():
+    """BASELINE config 3 (multi-scale {320..608}): one Network / TrainStep takes batches of different resolutions step by
+    step - every arena, loss configuration and target grid is keyed by the input size, weights and Adam state are shared."""
+    import torch
+    from multigriddet_amd.engine import Network
+    from multigriddet_amd.train_step import TrainStep
+    import bench
+    dev = torch.device("cuda:0")
+    net = Network(80, 3, dev, seed=0)
+    ts = TrainStep(net, bench.coco_anchors(), 80, (320, 320), 4, lr=1e-4)
+    sizes = [320, 352, 416, 320, 352, 416, 320]
+    batches = {}
+    for s in set(sizes):
+        img, bx = bench.synth_batch(s, 4, s)
+        batches[s] = (torch.from_numpy(img).to(dev), torch.from_numpy(bx).to(dev))
+    first, last = {}, {}
+    for s in sizes:
+        comp = ts.step(*batches[s])
+        v = float(comp[7])
+        assert np.isfinite(v)
+        first.setdefault(s, v)
+        last[s] = v
+    torch.cuda.synchronize()
+    assert ts.step_count == len(sizes)
+    assert last[320] < first[320]            # the shared weights keep training across resolutions
