@@ -97,8 +97,10 @@ typedef struct mgd_wgrad_desc {
 
 int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream);
 
-/* Stem conv 3x3, Cin=3 -> Cout=32, stride 1, 'same' (models/backbones/darknet.py:21): direct
- * (non-MFMA, HBM-bound) kernels.  image f32 [N,H,W,3]; w f32 [32][3][3][3] (OHWI); y bf16 [N,H,W,32]. */
+/* Stem conv 3x3, Cin=3 -> Cout=32, stride 1, 'same' (models/backbones/darknet.py:21).  image f32 [N,H,W,3];
+ * w f32 [32][3][3][3] (OHWI); y bf16 [N,H,W,32].  mgd_stem_fwd runs on the matrix cores straight from the fp32 image
+ * (image and weights rounded to bf16, fp32 accumulation, K = 27 of one 32-deep MFMA) with the BatchNorm statistics
+ * epilogue; mgd_stem_wgrad is the direct fp32 kernel (the engine uses mgd_stem_im2col + mgd_conv_wgrad instead). */
 int mgd_stem_fwd(const float* image, const float* w, void* y, float* stats, int stats_replicas, int N, int H,
                  int W, void* stream);
 int mgd_stem_wgrad(const float* image, const void* dy, float* dw, int N, int H, int W, void* stream);

@@ -1970,69 +1970,108 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
 
 // ------------------------------------------------------------------------------------------------
 // Stem: 3x3, 3 -> 32, fp32 image in, bf16 out.  HBM-bound (writes 64 B per pixel); direct VALU.
+// Stem forward on the matrix cores, straight from the fp32 image (no im2col image in HBM): a block owns 4 rows x 64
+// pixels of one image; the haloed fp32 patch (6 x 66 pixels x 3 channels) is staged in LDS with coalesced loads; a
+// wave takes one row and builds, 16 pixels at a time, the B fragment of v_mfma_f32_16x16x32_bf16 from eight LDS
+// words per lane (k = tap*3 + c; the three taps of a kernel row are nine consecutive floats of the patch row) -
+// K = 27 of 32, weights as two A fragments held in registers.  Same arithmetic as the im2col + GEMM path it replaces
+// (bf16-rounded image and weights, fp32 accumulation), reads 71 MB + writes 378 MB instead of 71+378 + 378+378 MB.
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                        bf16_t* __restrict__ y, float* stats, int reps, int N, int H,
                                                        int W) {
-  __shared__ float ws[32 * 27];
-  __shared__ float red[2][32];
-  for (int i = threadIdx.x; i < 32 * 27; i += 256) ws[i] = w[i];
-  if (threadIdx.x < 64) red[threadIdx.x >> 5][threadIdx.x & 31] = 0.f;
-  __syncthreads();
-  // 256 threads = 64 pixels x 4 channel-octets
-  const int oct = threadIdx.x & 3;
-  const long long P = (long long)N * H * W;
-  float s1[8], s2[8];
+  constexpr int TH = 4, TW = 64, PR = TH + 2, PCF = (TW + 2) * 3;      // patch rows, floats per patch row
+  __shared__ float patch[PR * PCF];
+  __shared__ float red[4][2][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tilesW = (W + TW - 1) / TW, tilesH = (H + TH - 1) / TH;
+  int b = blockIdx.x;
+  const int tw = b % tilesW; b /= tilesW;
+  const int th = b % tilesH;
+  const int n = b / tilesH;
+  const int h0 = th * TH, w0 = tw * TW;
+  for (int i = tid; i < PR * PCF; i += 256) {
+    int pr = i / PCF, off = i - pr * PCF;
+    int hh = h0 - 1 + pr;
+    int col = (w0 - 1) * 3 + off;                 // float index inside the image row
+    float v = 0.f;
+    if ((unsigned)hh < (unsigned)H && (unsigned)col < (unsigned)(W * 3)) v = img[((long long)n * H + hh) * W * 3 + col];
+    patch[i] = v;
+  }
+  // A fragments: lane (fr = cout within the 16-row tile, fq = k group) holds w[m*16 + fr][fq*8 .. +7]
+  const int fr = lane & 15, fq = lane >> 4;
+  bf16x8 wf[2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-  for (long long p = (long long)blockIdx.x * 64 + (threadIdx.x >> 2); p < P; p += (long long)gridDim.x * 64) {
-    int wx = (int)(p % W);
-    long long t = p / W;
-    int hy = (int)(t % H);
-    int n = (int)(t / H);
-    float in[27];
+  for (int m = 0; m < 2; ++m) {
+    float t[8];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        int hh = hy + kh - 1, ww = wx + kw - 1;
-        bool v = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-        const float* q = img + (((long long)n * H + hh) * W + ww) * 3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) in[(kh * 3 + kw) * 3 + c] = v ? q[c] : 0.f;
-      }
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float* wr = ws + (oct * 8 + j) * 27;
-      float acc = 0.f;
-#pragma unroll
-      for (int k = 0; k < 27; ++k) acc = fmaf(in[k], wr[k], acc);
-      o[j] = acc;
+    for (int i = 0; i < 8; ++i) {
+      int k = fq * 8 + i;
+      t[i] = k < 27 ? w[(m * 16 + fr) * 27 + k] : 0.f;
     }
-    uint4 pk = pack8(o);
-    *(uint4*)(y + p * 32 + oct * 8) = pk;
-    float r[8];
-    unpack8(pk, r);
+    wf[m] = __builtin_bit_cast(bf16x8, pack8(t));
+  }
+  // B fragment gather offsets (patch floats relative to the pixel's row start): k -> (k / 9) rows down, (k % 9) floats right
+  int koff[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] += r[j]; s2[j] += r[j] * r[j]; }
+  for (int i = 0; i < 8; ++i) {
+    int k = fq * 8 + i;
+    koff[i] = k < 27 ? (k / 9) * PCF + (k % 9) : -1;
+  }
+  __syncthreads();
+  const int hy = h0 + wave;
+  float s1[2][4], s2[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
+  if (hy < H) {
+#pragma unroll
+    for (int j = 0; j < TW / 16; ++j) {
+      const int px = j * 16 + fr;
+      const float* base = patch + wave * PCF + px * 3;
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = koff[i] >= 0 ? base[koff[i]] : 0.f;
+      bf16x8 xf = __builtin_bit_cast(bf16x8, pack8(t));
+      const bool ok = w0 + px < W;
+      bf16_t* yr = y + (((long long)n * H + hy) * W + w0 + px) * 32;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        uint2 pk;
+        pk.x = pack2bf(acc[0], acc[1]);
+        pk.y = pack2bf(acc[2], acc[3]);
+        if (ok) {
+          *(uint2*)(yr + m * 16 + fq * 4) = pk;
+          float v0 = __uint_as_float(pk.x << 16), v1 = __uint_as_float(pk.x & 0xffff0000u);
+          float v2 = __uint_as_float(pk.y << 16), v3 = __uint_as_float(pk.y & 0xffff0000u);
+          s1[m][0] += v0; s1[m][1] += v1; s1[m][2] += v2; s1[m][3] += v3;
+          s2[m][0] = fmaf(v0, v0, s2[m][0]); s2[m][1] = fmaf(v1, v1, s2[m][1]);
+          s2[m][2] = fmaf(v2, v2, s2[m][2]); s2[m][3] = fmaf(v3, v3, s2[m][3]);
+        }
+      }
+    }
   }
   if (stats) {
+    // lanes with equal fq hold the same channels: fold the 16 pixel lanes, one partial row per wave, then per block
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      // lanes with equal (lane & 3) hold the same channel octet
-      float a = s1[j], b = s2[j];
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int o = 32; o >= 4; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-      if ((threadIdx.x & 63) < 4) {
-        atomicAdd(&red[0][oct * 8 + j], a);
-        atomicAdd(&red[1][oct * 8 + j], b);
+      for (int r = 0; r < 4; ++r) {
+        float x1 = s1[m][r], x2 = s2[m][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
+        if (fr == 0) {
+          red[wave][0][m * 16 + fq * 4 + r] = x1;
+          red[wave][1][m * 16 + fq * 4 + r] = x2;
+        }
       }
-    }
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (tid < 64) {
+      int which = tid >> 5, c = tid & 31;
+      float t = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
       int rep = blockIdx.x % reps;
-      atomicAdd(stats + ((long long)rep * 2 + (threadIdx.x >> 5)) * 32 + (threadIdx.x & 31),
-                red[threadIdx.x >> 5][threadIdx.x & 31]);
+      atomicAdd(stats + ((long long)rep * 2 + which) * 32 + c, t);
     }
   }
 }
@@ -2493,10 +2532,9 @@ extern "C" int mgd_stem_fwd(const float* image, const float* w, void* y, float* 
                             int H, int W, void* stream) {
   MGD_REQUIRE(image && w && y, "stem_fwd: null pointer");
   MGD_REQUIRE(!stats || stats_replicas >= 1, "stem_fwd: stats_replicas");
-  long long P = (long long)N * H * W;
-  int grid = (int)((P + 63) / 64);
-  if (grid > 256 * 16) grid = 256 * 16;
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, image, w, (bf16_t*)y, stats,
+  MGD_REQUIRE(N >= 1 && H >= 1 && W >= 1 && (long long)N * H * W * 3 < (1ll << 31), "stem_fwd: N=%d H=%d W=%d", N, H, W);
+  long long grid = (long long)N * ((H + 3) / 4) * ((W + 63) / 64);
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, image, w, (bf16_t*)y, stats,
                      stats_replicas > 0 ? stats_replicas : 1, N, H, W);
   MGD_CHECK_LAUNCH("stem_fwd");
   return MGD_OK;

@@ -107,7 +107,7 @@ class Network:
             else:
                 cv.bias = self.params[cv.off_a:cv.off_a + C]
                 cv.dbias = self.grads[cv.off_a:cv.off_a + C]
-            if cv.role == "stem":       # 3x3x3 -> 32 runs as a 1x1 GEMM over the bf16 im2col image (K = 27 of 32)
+            if cv.role == "stem":       # weight gradient: 1x1 GEMM over the bf16 im2col image (K = 27 of 32)
                 cv.pk = ops.PackedConv(cv.cout, 32, 1, 1, dev, need_dgrad=False, ci_master=27)
                 cv.wpack = cv.w.view(cv.cout, 1, 27)
             else:
@@ -266,9 +266,10 @@ class Network:
         cv = self.layers[i]
         tr = self._bn_training(cv)
         y = A["y"][i]
-        if cv.role == "stem":
-            x = ops.stem_im2col(x, out=A["im2col"])
-        ops.conv_fwd(x, cv.pk, out=y, stats=cv.stats if tr else None)
+        if cv.role == "stem":       # matrix-core stem straight from the fp32 image (no im2col image in the forward pass)
+            ops.stem_fwd(x, cv.w, out=y, stats=cv.stats if tr else None)
+        else:
+            ops.conv_fwd(x, cv.pk, out=y, stats=cv.stats if tr else None)
         P = y.numel() // cv.cout
         return ops.bn_act_fwd_fused(cv.stats, float(P), cv.gamma, cv.beta, cv.mm, cv.mv, cv.scale, cv.shift,
                                     cv.smean, cv.sinv, y, A["a"][i], residual=residual, training=tr)
@@ -359,6 +360,15 @@ class Network:
         def inp(i):
             return fin[i]
 
+        if not (train_head_only or pred_only):
+            # the stem's weight gradient runs as a GEMM over the bf16 im2col image of the input: build it now, on the
+            # weight-gradient stream, where it hides under the head's backward pass
+            side = self.wg_stream if self.overlap_wgrad else torch.cuda.current_stream()
+            ev0 = torch.cuda.Event()
+            ev0.record()
+            side.wait_event(ev0)
+            with torch.cuda.stream(side):
+                ops.stem_im2col(A["image"], out=A["im2col"])
         head0 = BACKBONE_CONVS
         d_up = {}            # grads for lateral activations, keyed by scale
         d_skip = {}          # grads for the backbone taps

@@ -138,6 +138,14 @@ def test_stem(dev):
     yb = y.float().cpu().view(-1, 32)
     np.testing.assert_allclose(stats.sum(0)[0].cpu().numpy(), yb.sum(0).numpy(), rtol=1e-3, atol=1e-2)
     np.testing.assert_allclose(stats.sum(0)[1].cpu().numpy(), (yb * yb).sum(0).numpy(), rtol=1e-3, atol=1e-2)
+    # the matrix-core stem equals the im2col + 1x1 GEMM path it replaced (same bf16 rounding, K = 27 in one MFMA)
+    col = ops.stem_im2col(img.to(dev))
+    pk = ops.PackedConv(32, 32, 1, 1, dev, need_dgrad=False, ci_master=27)
+    pk.refresh(w.to(dev).view(32, 1, 27))
+    y2 = ops.conv_fwd(col, pk)
+    torch.cuda.synchronize()
+    assert (y.float() - y2.float()).abs().max().item() <= 1e-2 * y2.float().abs().max().item()
+    assert (y == y2).float().mean().item() > 0.99
     dy = bf(torch.randn(2, 40, 48, 32, generator=g))
     yr.backward(dy.float())
     dw = torch.zeros(32, 9, 3, device=dev)

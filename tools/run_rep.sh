@@ -1,4 +1,4 @@
 set -e
-timeout -k 10 300 python -m pytest tests/test_gpu_engine.py -x -q -m gpu -k "multiscale" 2>&1 | tail -3
-for m in diou soft wbf; do timeout -k 10 200 python tools/bench_infer.py --method $m 2>&1 | grep -v amdgpu | tail -1; done
-timeout -k 10 200 python tools/bench_infer.py --batch 1 --steps 100 2>&1 | grep -v amdgpu | tail -1
+timeout -k 10 300 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_engine.py -x -q -m gpu 2>&1 | tail -3
+timeout -k 10 100 python tools/bench_stem.py 2>&1 | grep -v amdgpu | tail -2
+timeout -k 10 200 python tools/ab_step.py overlap_wgrad=1 2>&1 | grep -v amdgpu
