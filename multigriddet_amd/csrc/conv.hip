@@ -2078,38 +2078,114 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 
 // dW[co][tap][c] = sum_p dy[p][co] * img[p (+) tap][c] ; 864 outputs reduced over all pixels.
 // thread = (channel co = tid & 31, pixel lane = tid >> 5): 27 private accumulators.
+// Stem weight gradient on the matrix cores: dW[co][k] += sum_p dy[p][co] * x[p (+) tap][c], k = tap*3 + c (27 of 32).
+// A block walks tiles of 4 rows x 64 pixels; per tile it stages the haloed fp32 image patch and the bf16 dy tile in
+// LDS, each wave takes one row (two 32-pixel K-steps): the A fragments (dy transposed) come from ds_read_b64_tr_b16,
+// the B fragments (the im2col matrix transposed, never materialised) are eight patch words per lane at stride 3.
+// Accumulators stay in registers over all tiles of the block; one 32x27 fp32 atomic flush per block.  Image rounded to
+// bf16 like the forward pass.
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy,
                                                          float* dw, int N, int H, int W) {
-  __shared__ float red[32 * 27];
-  for (int i = threadIdx.x; i < 32 * 27; i += 256) red[i] = 0.f;
-  __syncthreads();
-  const int co = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const long long P = (long long)N * H * W;
-  float acc[27];
+  constexpr int TH = 4, TW = 64, PR = TH + 2, PCF = (TW + 2) * 3;
+  __shared__ float patch[PR * PCF];
+  __shared__ __attribute__((aligned(16))) unsigned char dyt[TH * TW * 64];     // [row][pixel][32 ch] bf16, tr-swizzled
+  __shared__ float red[32 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tilesW = (W + TW - 1) / TW, tilesH = (H + TH - 1) / TH;
+  const int ntiles = N * tilesH * tilesW;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pl = lane & 3;
+  // B gather: lane = column k (per 16-wide tile nt) and pixel group fq*8.. ; offsets of the k-th im2col column in the patch
+  int koff[2];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-  for (long long p = (long long)blockIdx.x * 8 + pl; p < P; p += (long long)gridDim.x * 8) {
-    int wx = (int)(p % W);
-    long long t = p / W;
-    int hy = (int)(t % H);
-    int n = (int)(t / H);
-    float g = bf2f(dy[p * 32 + co]);
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        int hh = hy + kh - 1, ww = wx + kw - 1;
-        if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) {
-          const float* q = img + (((long long)n * H + hh) * W + ww) * 3;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) acc[(kh * 3 + kw) * 3 + c] = fmaf(g, q[c], acc[(kh * 3 + kw) * 3 + c]);
-        }
-      }
+  for (int nt = 0; nt < 2; ++nt) {
+    int k = nt * 16 + fr;
+    koff[nt] = k < 27 ? (k / 9) * PCF + (k % 9) : -1;
   }
+  // A (dy^T) transposed reads: MFMA k index = pixel kk*32 + 8g + qq (+4 for the upper half), channel group m
+  int o_rd[2][2][2];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) atomicAdd(&red[co * 27 + k], acc[k]);
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int r0 = kk * 32 + 8 * g + qq + 4 * h;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) o_rd[kk][h][m] = (wave * TW + r0) * 64 + ((m ^ tr_swz(r0, 2)) * 32) + pl * 8;
+    }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const unsigned dyt_a = lds_addr(dyt);
+
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    int b = t;
+    const int tw = b % tilesW; b /= tilesW;
+    const int th = b % tilesH;
+    const int n = b / tilesH;
+    const int h0 = th * TH, w0 = tw * TW;
+    __syncthreads();                                  // previous tile's reads are done
+    for (int i = tid; i < PR * PCF; i += 256) {
+      int pr = i / PCF, off = i - pr * PCF;
+      int hh = h0 - 1 + pr;
+      int col = (w0 - 1) * 3 + off;
+      float v = 0.f;
+      if ((unsigned)hh < (unsigned)H && (unsigned)col < (unsigned)(W * 3)) v = img[((long long)n * H + hh) * W * 3 + col];
+      patch[i] = v;
+    }
+    for (int i = tid; i < TH * TW * 4; i += 256) {    // 16-byte chunks of the dy tile
+      int ch = i & 3, px = (i >> 2) % TW, r = i / (4 * TW);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (h0 + r < H && w0 + px < W) v = *(const uint4*)(dy + (((long long)n * H + h0 + r) * W + w0 + px) * 32 + ch * 8);
+      int slot = ((((ch >> 1) ^ tr_swz(px, 2)) << 1) | (ch & 1));
+      *(uint4*)(dyt + (r * TW + px) * 64 + slot * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      s16x4 fa[2][2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        tr_read_asm<0>(fa[m][0], dyt_a + o_rd[kk][0][m]);
+        tr_read_asm<0>(fa[m][1], dyt_a + o_rd[kk][1][m]);
+      }
+      bf16x8 xf[2];
+      const float* base = patch + wave * PCF + (kk * 32 + fq * 8) * 3;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float tv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tv[i] = koff[nt] >= 0 ? base[koff[nt] + i * 3] : 0.f;
+        xf[nt] = __builtin_bit_cast(bf16x8, pack8(tv));
+      }
+      wait_lgkm_dyn(0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        touch(fa[m][0]); touch(fa[m][1]);
+        s16x8 av = __builtin_shufflevector(fa[m][0], fa[m][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), xf[nt], acc[m][nt], 0, 0, 0);
+      }
+    }
+  }
+  // fold the four waves, then one atomic per (co, k)
   __syncthreads();
-  for (int i = threadIdx.x; i < 32 * 27; i += 256) atomicAdd(dw + i, red[i]);
+  for (int i = tid; i < 32 * 32; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[(m * 16 + fq * 4 + r) * 32 + nt * 16 + fr], acc[m][nt][r]);
+  __syncthreads();
+  for (int i = tid; i < 32 * 32; i += 256) {
+    int co = i >> 5, k = i & 31;
+    if (k < 27) atomicAdd(dw + co * 27 + k, red[i]);
+  }
 }
 
 
@@ -2542,9 +2618,9 @@ extern "C" int mgd_stem_fwd(const float* image, const float* w, void* y, float* 
 
 extern "C" int mgd_stem_wgrad(const float* image, const void* dy, float* dw, int N, int H, int W, void* stream) {
   MGD_REQUIRE(image && dy && dw, "stem_wgrad: null pointer");
-  long long P = (long long)N * H * W;
-  int grid = (int)((P + 7) / 8);
-  if (grid > 256 * 8) grid = 256 * 8;
+  MGD_REQUIRE(N >= 1 && H >= 1 && W >= 1 && (long long)N * H * W * 3 < (1ll << 31), "stem_wgrad: N=%d H=%d W=%d", N, H, W);
+  long long tiles = (long long)N * ((H + 3) / 4) * ((W + 63) / 64);
+  int grid = (int)(tiles < 256 * 4 ? tiles : 256 * 4);
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, image, (const bf16_t*)dy, dw,
                      N, H, W);
   MGD_CHECK_LAUNCH("stem_wgrad");

@@ -107,15 +107,14 @@ class Network:
             else:
                 cv.bias = self.params[cv.off_a:cv.off_a + C]
                 cv.dbias = self.grads[cv.off_a:cv.off_a + C]
-            if cv.role == "stem":       # weight gradient: 1x1 GEMM over the bf16 im2col image (K = 27 of 32)
-                cv.pk = ops.PackedConv(cv.cout, 32, 1, 1, dev, need_dgrad=False, ci_master=27)
-                cv.wpack = cv.w.view(cv.cout, 1, 27)
+            if cv.role == "stem":       # forward and weight gradient read the fp32 master weights / image directly
+                cv.pk = None
+                cv.wpack = None
             else:
                 cv.pk = ops.PackedConv(cv.cout, cv.cin, cv.k, cv.s, dev, need_dgrad=True)
                 cv.wpack = cv.w
-        self._pack_all = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers], dev)
+        self._pack_all = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers if cv.pk is not None], dev)
         self._pack_head = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers[BACKBONE_CONVS:]], dev)
-        self._stem_dw = torch.zeros(32, 1, 32, dtype=torch.float32, device=dev)
         self.training = True
         self.freeze_backbone = False
         self.freeze_all_but_pred = False
@@ -239,7 +238,6 @@ class Network:
                 A["cat"][sc] = torch.empty(B, 2 * gh, 2 * gw, lat.cout + skip_c, dtype=bf, device=dev)
                 i += 1
                 gh, gw = gh * 2, gw * 2
-        A["im2col"] = torch.empty(B, H, W, 32, dtype=bf, device=dev)
         A["scratch"] = {}
         self._arenas[key] = A
         return A
@@ -360,15 +358,6 @@ class Network:
         def inp(i):
             return fin[i]
 
-        if not (train_head_only or pred_only):
-            # the stem's weight gradient runs as a GEMM over the bf16 im2col image of the input: build it now, on the
-            # weight-gradient stream, where it hides under the head's backward pass
-            side = self.wg_stream if self.overlap_wgrad else torch.cuda.current_stream()
-            ev0 = torch.cuda.Event()
-            ev0.record()
-            side.wait_event(ev0)
-            with torch.cuda.stream(side):
-                ops.stem_im2col(A["image"], out=A["im2col"])
         head0 = BACKBONE_CONVS
         d_up = {}            # grads for lateral activations, keyed by scale
         d_skip = {}          # grads for the backbone taps
@@ -473,9 +462,7 @@ class Network:
         side = self.wg_stream if self.overlap_wgrad else torch.cuda.current_stream()
         side.wait_event(ev)
         with torch.cuda.stream(side):
-            self._stem_dw.zero_()
-            ops.conv_wgrad(A["im2col"], dy0, self._stem_dw, 1, 1)
-            Lr[0].dw.view(32, 27).add_(self._stem_dw.view(32, 32)[:, :27])
+            ops.stem_wgrad(A["image"], dy0, Lr[0].dw)        # matrix cores, straight from the fp32 image
         self._join_wgrad()
         if on_layer_done:
             on_layer_done(0)
