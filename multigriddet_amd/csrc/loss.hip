@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int MAXL = 4, MAXA = 8;
-constexpr int CELLS_PER_BLOCK = 64;
+constexpr int CELLS_PER_BLOCK = 64;     // upper bound; the launch picks fewer on the small grids (see mgd_loss_fwd_bwd)
 constexpr int GT_LDS = 1024;
 constexpr float KEPS = 1e-7f;
 
@@ -82,7 +82,7 @@ __global__ void loss_prep_kernel(LossArgs a, int l) {
 }
 
 // ---- K2: per-cell loss and gradient.  grid = (cells chunks, B, 1) per scale.
-__global__ __launch_bounds__(256) void loss_cell_kernel(LossArgs a, int l) {
+__global__ __launch_bounds__(256) void loss_cell_kernel(LossArgs a, int l, int cpb) {
   const mgd_loss_cfg& c = a.cfg;
   const int gh = c.grid_h[l], gw = c.grid_w[l], A = c.A, C = c.C, F = 5 + A + C;
   const int b = blockIdx.y;
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void loss_cell_kernel(LossArgs a, int l) {
   const float gscale = c.grad_out_scale;
 
   float s_loc = 0.f, s_obj = 0.f, s_anc = 0.f, s_cls = 0.f;
-  const int cell_beg = blockIdx.x * CELLS_PER_BLOCK;
-  const int cell_end = min(gh * gw, cell_beg + CELLS_PER_BLOCK);
+  const int cell_beg = blockIdx.x * cpb;
+  const int cell_end = min(gh * gw, cell_beg + cpb);
   for (int cell = cell_beg + wave; cell < cell_end; cell += 4) {
     const long long gcell = (long long)b * gh * gw + cell;
     const float* p = a.yp[l] + gcell * F;
@@ -433,8 +433,14 @@ extern "C" int mgd_loss_fwd_bwd(const mgd_loss_cfg* cfg, const float* const* y_p
   for (int l = 0; l < cfg->L; ++l) {
     LossArgs al = a;
     if (scratch_used[l]) al.gb[l] = nullptr;    // bf16 image is produced after the consensus scatter
-    int gx = cdiv(cfg->grid_h[l] * cfg->grid_w[l], CELLS_PER_BLOCK);
-    hipLaunchKernelGGL(loss_cell_kernel, dim3(gx, cfg->B), dim3(256), 0, st, al, l);
+    // a wave walks its cells one after the other and every cell is a dependent chain of global loads, so the launch
+    // is latency bound: 64 cells per block left the 19x19 grid on 96 blocks (69 us for 5776 cells).  Aim for >= 2048
+    // blocks; the per-block cost that grows with it is the GT list staged in LDS (<= 16 KB, usually ~1.5 KB).
+    const int cells = cfg->grid_h[l] * cfg->grid_w[l];
+    int cpb = CELLS_PER_BLOCK;
+    while (cpb > 4 && (long long)cdiv(cells, cpb) * cfg->B < 2048) cpb >>= 1;
+    int gx = cdiv(cells, cpb);
+    hipLaunchKernelGGL(loss_cell_kernel, dim3(gx, cfg->B), dim3(256), 0, st, al, l, cpb);
   }
   if (cfg->use_consensus_loss) {
     for (int l = 0; l < cfg->L; ++l) {
