@@ -361,13 +361,25 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict
   const int PL = 256 / CV;
   const int oct = threadIdx.x % CV, pl = threadIdx.x / CV;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (pl < PL)
-    for (long long p = (long long)blockIdx.x * PL + pl; p < P; p += (long long)gridDim.x * PL) {
-      float f[8];
-      unpack8(*(const uint4*)(dy + p * C + oct * 8), f);
+  if (pl < PL) {
+    constexpr int U = 4;                       // loads in flight per thread (the loop is otherwise one dependent load)
+    const long long stride = (long long)gridDim.x * PL;
+    for (long long p0 = (long long)blockIdx.x * PL + pl; p0 < P; p0 += stride * U) {
+      uint4 v[U];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s[j] += f[j];
+      for (int u = 0; u < U; ++u) {
+        long long p = p0 + u * stride;
+        v[u] = p < P ? *(const uint4*)(dy + p * C + oct * 8) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float f[8];
+        unpack8(v[u], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += f[j];
+      }
     }
+  }
   if (pl < PL)
 #pragma unroll
     for (int j = 0; j < 8; ++j) atomicAdd(&red[oct * 8 + j], s[j]);
