@@ -1105,6 +1105,123 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
   epi.run(a, acc, smem, row_dst, co0, ltid);
 }
 
+// ------------------------------------------------------------------------------------------------
+// "Patch" form of the 3x3 gather-GEMM for the thin early layers (CI, CO <= 64: all nine taps of the weights fit in
+// LDS).  The v2 kernel walks K = 9*CI in 64-deep steps and is bound by one LDS-DMA round trip per step (1.63 us), i.e.
+// by nothing the layer itself needs: the input is re-read nine times through L2.  Here a persistent block keeps the
+// weights in LDS as ready-made A fragments (9 x CI/32 x CO/16 KiB), and per tile of 8 x 16 output pixels (4 x 16 at
+// stride 2) stages the haloed input patch ONCE (plain 16-byte loads, padded pixel pitch -> conflict-free
+// ds_read_b128), then runs the nine taps out of LDS.  Same epilogue as the other forms (GemmEpilogue).
+template <int CI, int CO, int S>
+__global__ __launch_bounds__(256) void conv_patch_kernel(GemmArgs a) {
+  constexpr int MT = CO / 16, KS = CI / 32, NT = 2 / S;
+  constexpr int TR = 8 / S, TC = 16;                 // output tile: 8 x 16 pixels (4 x 16 at stride 2), NT rows per wave
+  constexpr int BMP = TR * TC;
+  using Epi = GemmEpilogue<1, 4, MT, NT>;
+  constexpr int PRW = (TR - 1) * S + 3, PCL = (TC - 1) * S + 3;     // patch rows / cols
+  constexpr int PB = CI * 2, PITCH = PB + 16;        // bytes per patch pixel, padded
+  constexpr int CPP = PB / 16;                       // 16-byte chunks per pixel
+  constexpr int NCH = PRW * PCL * CPP;               // chunks per patch
+  constexpr int PL = (NCH + 255) / 256;              // chunks per thread
+  constexpr int WBYTES = 9 * KS * MT * 1024;
+  constexpr int PBYTES = ((PRW * PCL * PITCH + 15) / 16) * 16;
+  constexpr int EBYTES = BMP * (CO * 2 + 16) + 4 * 2 * CO * 4;
+  constexpr int UBYTES = PBYTES > EBYTES ? PBYTES : EBYTES;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wl = smem;                          // A fragments: [(t*KS + ks)*MT + m][lane] x 16 B
+  unsigned char* pt = smem + WBYTES;                 // patch ...
+  unsigned char* el = pt;                            // ... reused by the epilogue tile + partial sums
+  long long* row_dst = (long long*)(smem + WBYTES + UBYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  // weights -> LDS once per block: lane (fr = co, fq = ci group) of fragment (t, ks, m) = 16 contiguous bytes of the
+  // packed image row co, at k = t*CI + ks*32 + fq*8
+  for (int f = wave; f < 9 * KS * MT; f += 4) {
+    int m = f % MT, ks = (f / MT) % KS, t = f / (MT * KS);
+    *(uint4*)(wl + f * 1024 + lane * 16) =
+        *(const uint4*)(a.wpk + (long long)(m * 16 + fr) * a.K_pad + t * CI + ks * 32 + fq * 8);
+  }
+  const int tilesW = (a.Wg + TC - 1) / TC, tilesH = (a.Hg + TR - 1) / TR;
+  const int ntiles = a.N * tilesH * tilesW;
+  int pbase[NT];                                      // my pixel fragments: tile rows NT*wave .. (slot = row*16 + col)
+#pragma unroll
+  for (int n = 0; n < NT; ++n) pbase[n] = (((wave * NT + n) * S) * PCL + fr * S) * PITCH + fq * 16;
+  // patch chunks of this thread: (patch pixel, 16-byte chunk) -> LDS offset, constant over tiles
+  int pp_r[PL], pp_c[PL], pp_o[PL], pp_ch[PL];
+#pragma unroll
+  for (int j = 0; j < PL; ++j) {
+    int i = tid + j * 256;
+    int ch = i % CPP, pp = i / CPP;
+    pp_r[j] = i < NCH ? pp / PCL : -100000;
+    pp_c[j] = pp % PCL;
+    pp_o[j] = pp * PITCH + ch * 16;
+    pp_ch[j] = ch * 8;
+  }
+  uint4 pre[PL];
+  auto fetch = [&](int t) {                           // haloed input patch of tile t -> registers
+    int b = t;
+    const int tw = b % tilesW; b /= tilesW;
+    const int th = b % tilesH;
+    const int n = b / tilesH;
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      int hh = th * TR * S - 1 + pp_r[j], ww = tw * TC * S - 1 + pp_c[j];
+      pre[j] = make_uint4(0, 0, 0, 0);
+      if ((unsigned)hh < (unsigned)a.Hs && (unsigned)ww < (unsigned)a.Ws)
+        pre[j] = *(const uint4*)(a.src + (((long long)n * a.Hs + hh) * a.Ws + ww) * CI + pp_ch[j]);
+    }
+  };
+  int t = blockIdx.x;
+  if (t < ntiles) fetch(t);
+  for (; t < ntiles; t += gridDim.x) {
+    int b = t;
+    const int tw = b % tilesW; b /= tilesW;
+    const int th = b % tilesH;
+    const int n = b / tilesH;
+    const int h0 = th * TR, w0 = tw * TC;
+    __syncthreads();                                  // previous tile's epilogue is done with the shared region
+    if (tid < BMP) {
+      int r = tid >> 4, c = tid & 15;
+      long long off = -1;
+      if (h0 + r < a.Hg && w0 + c < a.Wg) off = (((long long)n * a.Hd + h0 + r) * a.Wd + w0 + c) * a.Co;
+      row_dst[tid] = off;
+    }
+#pragma unroll
+    for (int j = 0; j < PL; ++j)
+      if (pp_r[j] >= 0) *(uint4*)(pt + pp_o[j]) = pre[j];
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);      // next tile's patch flies under this tile's MFMAs
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int nn = 0; nn < NT; ++nn) acc[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int toff = ((tp / 3) * PCL + (tp % 3)) * PITCH;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 wf[MT], xf[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(wl + ((tp * KS + ks) * MT + m) * 1024 + lane * 16);
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) xf[nn] = *(const bf16x8*)(pt + pbase[nn] + toff + ks * 64);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int nn = 0; nn < NT; ++nn)
+            acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[nn], acc[m][nn], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                  // every wave is done with the patch: the epilogue reuses its LDS
+    Epi epi;
+    epi.prefetch(a, row_dst, 0, tid, false);
+    epi.run(a, acc, el, row_dst, 0, tid);
+  }
+}
+
 template <int WC, int WP, int MT, int NT, int NST>
 __global__ __launch_bounds__(64 * WC * WP) void conv_gemm3_kernel(GemmArgs a) {
   // BK = 32 variant: tile rows are 64 B (4 chunks of 16 B), chunk c of row r stored at slot c ^ g((r>>2)&3)
@@ -2378,6 +2495,31 @@ int launch_gemm6(GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
+template <int CI, int CO, int S>
+int launch_patch(GemmArgs& a, hipStream_t st) {
+  constexpr int MT = CO / 16, KS = CI / 32;
+  constexpr int TR = 8 / S, TC = 16;
+  constexpr int PRW = (TR - 1) * S + 3, PCL = (TC - 1) * S + 3, PITCH = CI * 2 + 16;
+  size_t pbytes = (size_t)((PRW * PCL * PITCH + 15) / 16) * 16, ebytes = (size_t)(TR * TC) * (CO * 2 + 16) + (size_t)4 * 2 * CO * 4;
+  size_t lds = (size_t)9 * KS * MT * 1024 + (pbytes > ebytes ? pbytes : ebytes) + (size_t)(TR * TC) * 8;
+  a.tilesC = 1;
+  long long tiles = (long long)a.N * cdiv(a.Hg, TR) * cdiv(a.Wg, TC);
+  a.nblk = (int)tiles;
+  auto k = conv_patch_kernel<CI, CO, S>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  int per_cu = (int)(160 * 1024 / (lds + 512));
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  long long grid = 256ll * per_cu;
+  if (grid > tiles) grid = tiles;
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, a);
+  return 0;
+}
+
 template <int WC, int WP, int MT, int NT, int NST>
 int launch_gemm3(GemmArgs& a, hipStream_t st) {
   constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
@@ -2508,6 +2650,25 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   for (int t = 0; t < 9 && std9; ++t) std9 = d->dh[t] == t / 3 - 1 && d->dw[t] == t % 3 - 1;
   static int rowshift = -1;
   if (rowshift < 0) { const char* e = getenv("MGD_ROWSHIFT"); rowshift = e ? atoi(e) : 0; }   // opt-in: measured equal to v2 (the K-loop is not bound by LDS-DMA bytes)
+  // patch form for the thin early layers: 3x3 in the standard tap order, 32 -> 64 channels, stride 1 or 2, bf16 output
+  {
+    static int patch = -1;
+    if (patch < 0) { const char* e = getenv("MGD_PATCH"); patch = e ? atoi(e) : 1; }
+    bool std9p = d->ntaps == 9 && d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 && d->Hd == d->Hg &&
+                 d->Wd == d->Wg && !d->dst_f32 && !d->bias && d->K_pad >= 9 * d->Ci &&
+                 (d->in_stride == 1 || d->in_stride == 2) && d->Hs == d->Hg * d->in_stride && d->Ws == d->Wg * d->in_stride;
+    for (int t = 0; t < 9 && std9p; ++t) std9p = d->dh[t] == t / 3 - 1 && d->dw[t] == t % 3 - 1;
+    if (variant == 3 && patch && std9p && d->Ci == 32 && d->Co == 64 && d->Co_pad == 64) {
+      if (d->in_stride == 1) launch_patch<32, 64, 1>(a, st); else launch_patch<32, 64, 2>(a, st);
+      MGD_CHECK_LAUNCH("conv_gather_gemm(patch)");
+      return MGD_OK;
+    }
+    if (variant == 3 && patch && std9p && d->Ci == 64 && d->Co == 32 && d->Co_pad == 32 && d->in_stride == 1) {
+      launch_patch<64, 32, 1>(a, st);             // the stride-1 data gradient of a 32 -> 64 layer
+      MGD_CHECK_LAUNCH("conv_gather_gemm(patch)");
+      return MGD_OK;
+    }
+  }
   // producer/consumer form: wins when the launch has few tiles per CU or long K-loops (its single block per CU leaves
   // prologue and epilogue exposed, which two barrier-synchronous blocks per CU hide on the short-K, many-tile layers)
   static int pc = -1;

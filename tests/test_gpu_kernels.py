@@ -214,7 +214,8 @@ def test_bn_act_fwd_bwd(dev, C, P, res):
     assert e <= 0.02 * yr.grad.abs().max().item() + 1e-3
 
 
-@pytest.mark.parametrize("N,H,W,Ci,Co,k,s", [(2, 20, 20, 64, 128, 3, 1), (2, 24, 24, 32, 64, 3, 2), (3, 19, 19, 256, 128, 1, 1)])
+@pytest.mark.parametrize("N,H,W,Ci,Co,k,s", [(2, 20, 20, 64, 128, 3, 1), (2, 24, 24, 32, 64, 3, 2), (3, 19, 19, 256, 128, 1, 1),
+                                             (2, 44, 36, 32, 64, 3, 1)])      # patch-form data gradient (64 -> 32)
 def test_dgrad_fused_bn_reduction(dev, N, H, W, Ci, Co, k, s):
     """conv_dgrad(..., bnred=...) must leave in `sums` exactly what mgd_bn_act_bwd_reduce computes from its output."""
     from multigriddet_amd import ops
