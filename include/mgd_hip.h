@@ -79,6 +79,26 @@ typedef struct mgd_conv_desc {
 
 int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream);
 
+/* Stride-2 data gradient of a 3x3 conv with 32 input / 64 output channels (the first down-sampling layer,
+ * models/backbones/darknet.py:33-34 with ZeroPadding2D(((1,0),(1,0))): all four output-parity classes in one launch,
+ * dy read once (the generic route is four mgd_conv_gather_gemm launches).  wpk[c] / K_pad[c]: the packed transposed
+ * images of class c = ph*2 + pw as mgd_pack_weights writes them (taps in (kh, kw) order of the class).
+ * dx[n, 2i+ph, 2j+pw, :] (+ addend); optional fused BatchNorm-backward sums as in mgd_conv_desc. */
+typedef struct mgd_dgrad_s2_desc {
+  const void* dy;      /* bf16 [N, Ho, Wo, Co]  */
+  const void* wpk[4];  /* bf16 [32][K_pad[c]]    */
+  void* dx;            /* bf16 [N, H, W, Ci]     */
+  const void* addend;  /* optional bf16, dx layout */
+  int32_t K_pad[4];
+  int32_t N, Ho, Wo, Co, H, W, Ci;
+  int32_t stats_replicas;
+  const void* bn_y;
+  const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
+  float* bn_sums;
+  float bn_slope;
+} mgd_dgrad_s2_desc;
+int mgd_conv_dgrad_s2_patch(const mgd_dgrad_s2_desc* d, void* stream);
+
 /* Weight gradient: dW[co][t][ci] += sum_p dy[p][co] * src[p (+) tap t][ci]   (fp32 atomics).
  * Replaces the Conv2D kernel gradient of Keras autodiff (layers.py:43-49).  Geometry fields have
  * the forward conv's meaning (src = forward input, dy = gradient of the forward output, whose

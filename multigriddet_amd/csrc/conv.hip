@@ -644,6 +644,12 @@ struct GemmEpilogue {
   uint4 ypre[EPC], apre[EPC];
   float bnp[4][8];
   bool bnred, addpre;
+  float pr1[8], pr2[8];      // per-channel partial sums carried across tiles (persistent kernels: run<true> + flush)
+
+  __device__ __forceinline__ void init_deferred() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pr1[j] = pr2[j] = 0.f;
+  }
 
   __device__ __forceinline__ void prefetch(const GemmArgs& a, const long long* row_dst, int co0, int tid,
                                            bool sync = true) {
@@ -675,7 +681,9 @@ struct GemmEpilogue {
     }
   }
 
-  // call after a __syncthreads() that follows the last LDS read of the K-loop
+  // call after a __syncthreads() that follows the last LDS read of the K-loop.  DEFER: the per-channel sums stay in
+  // this thread's registers (pr1/pr2) instead of being reduced and added to global memory - flush() does that once.
+  template <bool DEFER = false>
   __device__ __forceinline__ void run(const GemmArgs& a, f32x4 (&acc)[MT][NT], unsigned char* smem,
                                       const long long* row_dst, int co0, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -757,6 +765,24 @@ struct GemmEpilogue {
         }
       }
     }
+    if (DEFER) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { pr1[j] += r1[j]; pr2[j] += r2[j]; }
+      return;
+    }
+    reduce_and_add(a, r1, r2, smem, co0, tid, stats, bnred);
+  }
+
+  // one flush per block of a persistent kernel (all threads; smem = the epilogue region, free at this point)
+  __device__ __forceinline__ void flush(const GemmArgs& a, unsigned char* smem, int co0, int tid) {
+    const bool stats = a.stats != nullptr;
+    const bool bnr = a.bn_y != nullptr && !a.dst_f32;
+    reduce_and_add(a, pr1, pr2, smem, co0, tid, stats, bnr);
+  }
+
+  __device__ __forceinline__ void reduce_and_add(const GemmArgs& a, float (&r1)[8], float (&r2)[8], unsigned char* smem,
+                                                 int co0, int tid, bool stats, bool bnred) {
+    const int lane = tid & 63, wave = tid >> 6;
     if (stats || bnred) {
       float* wred = (float*)(smem + BMP * (BNC * 2 + 16));
 #pragma unroll
@@ -1173,6 +1199,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(GemmArgs a) {
         pre[j] = *(const uint4*)(a.src + (((long long)n * a.Hs + hh) * a.Ws + ww) * CI + pp_ch[j]);
     }
   };
+  // per-channel sums (BatchNorm statistics / fused BN-backward sums) stay in registers over all tiles of the block
+  Epi epi;
+  epi.init_deferred();
   int t = blockIdx.x;
   if (t < ntiles) fetch(t);
   for (; t < ntiles; t += gridDim.x) {
@@ -1193,6 +1222,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(GemmArgs a) {
       if (pp_r[j] >= 0) *(uint4*)(pt + pp_o[j]) = pre[j];
     __syncthreads();
     if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);      // next tile's patch flies under this tile's MFMAs
+    epi.prefetch(a, row_dst, 0, tid, false);                     // and so do the epilogue's HBM operands
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -1216,10 +1246,153 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(GemmArgs a) {
       }
     }
     __syncthreads();                                  // every wave is done with the patch: the epilogue reuses its LDS
-    Epi epi;
-    epi.prefetch(a, row_dst, 0, tid, false);
-    epi.run(a, acc, el, row_dst, 0, tid);
+    epi.template run<true>(a, acc, el, row_dst, 0, tid);
   }
+  __syncthreads();
+  epi.flush(a, el, 0, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stride-2 data gradient of the first down-sampling layer (dy: 64 channels at 304 x 304 -> dx: 32 channels at 608 x
+// 608) in patch form, all four output-parity classes in one launch.  The generic path runs the four classes as four
+// gather-GEMM launches with K = 64..256 (1-4 K-steps per block, each launch re-reading dy): 402 us against a 125 us
+// HBM floor.  Here a persistent block keeps the nine transposed taps in LDS, stages the (8+1) x (16+1) dy patch of a
+// tile once, and accumulates the four classes side by side (tap kh feeds output rows of parity kh != 1, from dy row
+// i + (kh == 0)); each class then leaves through the common epilogue (addend, fused BatchNorm-backward sums).
+struct Dgrad2Args {
+  GemmArgs g;                 // dst / addend / bn_* / Co (= dx channels) / stats_replicas for the epilogue; src = dy
+  const bf16_t* wpk[4];       // class images [(ph, pw)] : [32 rows][ntaps_c * 64]
+  int K_pad[4];
+  int Ho, Wo, H, W;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void conv_patch_dgrad2_kernel(Dgrad2Args d) {
+  constexpr int KS = CIN / 32, MT = COUT / 16, NT = 2;
+  constexpr int TR = 8, TC = 16, BMP = TR * TC;
+  using Epi = GemmEpilogue<1, 4, MT, NT>;
+  constexpr int PRW = TR + 1, PCL = TC + 1;
+  constexpr int PB = CIN * 2, PITCH = PB + 16, CPP = PB / 16;
+  constexpr int NCH = PRW * PCL * CPP, PL = (NCH + 255) / 256;
+  constexpr int WBYTES = 9 * KS * MT * 1024;
+  constexpr int PBYTES = ((PRW * PCL * PITCH + 15) / 16) * 16;
+  constexpr int EBYTES = BMP * (COUT * 2 + 16) + 4 * 2 * COUT * 4;
+  const GemmArgs& a = d.g;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wl = smem;
+  unsigned char* pt = smem + WBYTES;                 // dy patch (kept over both output-row parities)
+  unsigned char* el = pt + PBYTES;                   // epilogue tile + partial sums
+  long long* row_dst = (long long*)(el + EBYTES);      // [2][BMP]: the two column parities of the current row parity
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  // transposed taps -> LDS as A fragments [(q*KS + ks)*MT + m], q = kh*3 + kw; tap (kh, kw) lives in the image of class
+  // (ph, pw) = (kh != 1, kw != 1) at slot (kh == 2) * (pw ? 2 : 1) + (kw == 2)
+  for (int f = wave; f < 9 * KS * MT; f += 4) {
+    int m = f % MT, ks = (f / MT) % KS, q = f / (MT * KS);
+    int kh = q / 3, kw = q - kh * 3;
+    int ph = kh != 1, pw = kw != 1;
+    int slot = (kh == 2 ? 1 : 0) * (pw ? 2 : 1) + (kw == 2 ? 1 : 0);
+    int c = ph * 2 + pw;
+    *(uint4*)(wl + f * 1024 + lane * 16) =
+        *(const uint4*)(d.wpk[c] + (long long)(m * 16 + fr) * d.K_pad[c] + slot * CIN + ks * 32 + fq * 8);
+  }
+  const int tilesW = (d.Wo + TC - 1) / TC, tilesH = (d.Ho + TR - 1) / TR;
+  const int ntiles = a.N * tilesH * tilesW;
+  int pbase[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) pbase[n] = ((wave * NT + n) * PCL + fr) * PITCH + fq * 16;
+  int pp_r[PL], pp_c[PL], pp_o[PL], pp_ch[PL];
+#pragma unroll
+  for (int j = 0; j < PL; ++j) {
+    int i = tid + j * 256;
+    int ch = i % CPP, pp = i / CPP;
+    pp_r[j] = i < NCH ? pp / PCL : 100000;
+    pp_c[j] = pp % PCL;
+    pp_o[j] = pp * PITCH + ch * 16;
+    pp_ch[j] = ch * 8;
+  }
+  uint4 pre[PL];
+  auto fetch = [&](int t) {
+    int b = t;
+    const int tw = b % tilesW; b /= tilesW;
+    const int th = b % tilesH;
+    const int n = b / tilesH;
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      int hh = th * TR + pp_r[j], ww = tw * TC + pp_c[j];
+      pre[j] = make_uint4(0, 0, 0, 0);
+      if (hh < d.Ho && ww < d.Wo)
+        pre[j] = *(const uint4*)(a.src + (((long long)n * d.Ho + hh) * d.Wo + ww) * CIN + pp_ch[j]);
+    }
+  };
+  Epi epi;                                           // fused BN-backward sums carried over all tiles, one flush per block
+  epi.init_deferred();
+  int t = blockIdx.x;
+  if (t < ntiles) fetch(t);
+  for (; t < ntiles; t += gridDim.x) {
+    int b = t;
+    const int tw = b % tilesW; b /= tilesW;
+    const int th = b % tilesH;
+    const int n = b / tilesH;
+    const int h0 = th * TR, w0 = tw * TC;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PL; ++j)
+      if (pp_r[j] < 100000) *(uint4*)(pt + pp_o[j]) = pre[j];
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+    // output rows of parity ph take the taps kh = 1 (ph = 0, dy row i) or kh = 0, 2 (ph = 1, dy rows i+1, i); the two
+    // column parities of a row parity are accumulated side by side and flushed before the other row parity starts
+    // (all four at once needed 254 VGPRs = one wave per SIMD)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      __syncthreads();                                // previous epilogues are done with row_dst and the tile
+      {
+        int pw = tid >> 7, sl = tid & 127, r = sl >> 4, cc = sl & 15;
+        long long off = -1;
+        if (h0 + r < d.Ho && w0 + cc < d.Wo)
+          off = (((long long)n * d.H + 2 * (h0 + r) + ph) * d.W + 2 * (w0 + cc) + pw) * a.Co;
+        row_dst[tid] = off;
+      }
+      __syncthreads();
+      epi.prefetch(a, row_dst, 0, tid, false);        // HBM operands of the first epilogue fly under the MFMAs
+      f32x4 acc[2][MT][NT];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int nn = 0; nn < NT; ++nn) acc[c][m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int kh = q / 3, kw = q % 3;
+        if ((kh != 1) != (ph == 1)) continue;
+        const int c = kw != 1;
+        const int toff = ((kh == 0) * PCL + (kw == 0)) * PITCH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 wf[MT], xf[NT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(wl + ((q * KS + ks) * MT + m) * 1024 + lane * 16);
+#pragma unroll
+          for (int nn = 0; nn < NT; ++nn) xf[nn] = *(const bf16x8*)(pt + pbase[nn] + toff + ks * 64);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nn = 0; nn < NT; ++nn)
+              acc[c][m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[nn], acc[c][m][nn], 0, 0, 0);
+        }
+      }
+      epi.template run<true>(a, acc[0], el, row_dst, 0, tid);
+      epi.prefetch(a, row_dst + BMP, 0, tid, false);  // (a second resident copy of the BN parameters spilled registers)
+      __syncthreads();                                // the tile is free again
+      epi.template run<true>(a, acc[1], el, row_dst + BMP, 0, tid);
+    }
+  }
+  __syncthreads();
+  epi.flush(a, el, 0, tid);
 }
 
 template <int WC, int WP, int MT, int NT, int NST>
@@ -2711,6 +2884,46 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     }
   }
   MGD_CHECK_LAUNCH("conv_gather_gemm");
+  return MGD_OK;
+}
+
+extern "C" int mgd_conv_dgrad_s2_patch(const mgd_dgrad_s2_desc* d, void* stream) {
+  MGD_REQUIRE(d && d->dy && d->dx && d->wpk[0] && d->wpk[1] && d->wpk[2] && d->wpk[3], "dgrad_s2_patch: null pointer");
+  MGD_REQUIRE(d->Co == 64 && d->Ci == 32, "dgrad_s2_patch: built for 64 -> 32 channels (got %d -> %d)", d->Co, d->Ci);
+  MGD_REQUIRE(d->H == 2 * d->Ho && d->W == 2 * d->Wo && d->N >= 1, "dgrad_s2_patch: geometry");
+  MGD_REQUIRE((long long)d->N * d->H * d->W * d->Ci < (1ll << 31), "dgrad_s2_patch: tensor too large");
+  MGD_REQUIRE(!d->bn_y || (d->bn_scale && d->bn_shift && d->bn_mean && d->bn_invstd && d->bn_sums && d->stats_replicas >= 1),
+              "dgrad_s2_patch: fused BN-backward reduction needs scale/shift/mean/invstd/sums and stats_replicas");
+  Dgrad2Args k;
+  GemmArgs& a = k.g;
+  a = GemmArgs{};
+  a.src = (const bf16_t*)d->dy; a.dst = d->dx; a.addend = (const bf16_t*)d->addend;
+  a.N = d->N; a.Co = d->Ci; a.Ci = d->Co; a.dst_f32 = 0; a.stats_replicas = d->stats_replicas > 0 ? d->stats_replicas : 1;
+  a.bn_y = (const bf16_t*)d->bn_y; a.bn_scale = d->bn_scale; a.bn_shift = d->bn_shift; a.bn_mean = d->bn_mean;
+  a.bn_invstd = d->bn_invstd; a.bn_sums = d->bn_sums; a.bn_slope = d->bn_slope;
+  for (int c = 0; c < 4; ++c) {
+    k.wpk[c] = (const bf16_t*)d->wpk[c];
+    k.K_pad[c] = d->K_pad[c];
+    int ntap = (c & 2 ? 2 : 1) * (c & 1 ? 2 : 1);
+    MGD_REQUIRE(d->K_pad[c] >= ntap * 64, "dgrad_s2_patch: K_pad[%d]=%d", c, d->K_pad[c]);
+  }
+  k.Ho = d->Ho; k.Wo = d->Wo; k.H = d->H; k.W = d->W;
+  constexpr int WB = 9 * 2 * 2 * 1024, PITCH = 64 * 2 + 16;
+  size_t pbytes = (size_t)((9 * 17 * PITCH + 15) / 16) * 16, ebytes = (size_t)128 * (32 * 2 + 16) + 4 * 2 * 32 * 4;
+  size_t lds = WB + pbytes + ebytes + 2 * 128 * 8;
+  auto kern = conv_patch_dgrad2_kernel<64, 32>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  long long tiles = (long long)d->N * cdiv(d->Ho, 8) * cdiv(d->Wo, 16);
+  int per_cu = (int)(160 * 1024 / (lds + 512));
+  if (per_cu > 4) per_cu = 4;
+  long long grid = 256ll * per_cu;
+  if (grid > tiles) grid = tiles;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, k);
+  MGD_CHECK_LAUNCH("conv_dgrad_s2_patch");
   return MGD_OK;
 }
 

@@ -193,6 +193,21 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
         d = _desc(dy, img, out, N, Ho, Wo, Co, H, W, H, W, pk.ci, 1, 1, (0, 0), dh, dw, kp, cp, addend=addend,
                   bnred=bnred)
         _launch_gemm(d, "conv_dgrad")
+    elif pk.k == 3 and pk.ci == 32 and pk.co == 64 and _S2_PATCH:
+        # the first down-sampling layer: all four parity classes in one patch-form launch (dy read once)
+        d = L.DgradS2Desc()
+        d.dy, d.dx = dy.data_ptr(), out.data_ptr()
+        d.addend = addend.data_ptr() if addend is not None else None
+        for c, (img, kp, cp, _, _) in enumerate(pk.dgrad):
+            d.wpk[c], d.K_pad[c] = img.data_ptr(), kp
+        d.N, d.Ho, d.Wo, d.Co, d.H, d.W, d.Ci = N, Ho, Wo, Co, H, W, pk.ci
+        d.stats_replicas = STATS_REPLICAS
+        if bnred is not None:
+            y, sc, sh, mu, iv, sums = bnred
+            d.bn_y, d.bn_scale, d.bn_shift = y.data_ptr(), sc.data_ptr(), sh.data_ptr()
+            d.bn_mean, d.bn_invstd, d.bn_sums = mu.data_ptr(), iv.data_ptr(), sums.data_ptr()
+            d.bn_slope = LEAKY_SLOPE
+        L.check(lib.mgd_conv_dgrad_s2_patch(C.byref(d), L.stream_ptr()), "conv_dgrad_s2_patch")
     else:
         for img, kp, cp, _, (ph, pw, tp) in pk.dgrad:
             d = _desc(dy, img, out, N, Ho, Wo, Co, H // 2, W // 2, H, W, pk.ci, 1, 2, (ph, pw),
@@ -202,6 +217,7 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
 
 
 import os as _os
+_S2_PATCH = _os.environ.get("MGD_S2_PATCH", "1") != "0"
 _WGRAD_BLOCKS = int(_os.environ.get("MGD_WGRAD_BLOCKS", "512"))
 
 
