@@ -2274,19 +2274,6 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   __shared__ float red[4][2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tilesW = (W + TW - 1) / TW, tilesH = (H + TH - 1) / TH;
-  int b = blockIdx.x;
-  const int tw = b % tilesW; b /= tilesW;
-  const int th = b % tilesH;
-  const int n = b / tilesH;
-  const int h0 = th * TH, w0 = tw * TW;
-  for (int i = tid; i < PR * PCF; i += 256) {
-    int pr = i / PCF, off = i - pr * PCF;
-    int hh = h0 - 1 + pr;
-    int col = (w0 - 1) * 3 + off;                 // float index inside the image row
-    float v = 0.f;
-    if ((unsigned)hh < (unsigned)H && (unsigned)col < (unsigned)(W * 3)) v = img[((long long)n * H + hh) * W * 3 + col];
-    patch[i] = v;
-  }
   // A fragments: lane (fr = cout within the 16-row tile, fq = k group) holds w[m*16 + fr][fq*8 .. +7]
   const int fr = lane & 15, fq = lane >> 4;
   bf16x8 wf[2];
@@ -2307,13 +2294,29 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     int k = fq * 8 + i;
     koff[i] = k < 27 ? (k / 9) * PCF + (k % 9) : -1;
   }
-  __syncthreads();
-  const int hy = h0 + wave;
-  float s1[2][4], s2[2][4];
+  float s1[2][4], s2[2][4];                        // BatchNorm statistics, carried over all tiles of the block
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
+  const int ntiles = N * tilesH * tilesW;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  int b = tile;
+  const int tw = b % tilesW; b /= tilesW;
+  const int th = b % tilesH;
+  const int n = b / tilesH;
+  const int h0 = th * TH, w0 = tw * TW;
+  __syncthreads();                                  // previous tile's patch reads are done
+  for (int i = tid; i < PR * PCF; i += 256) {
+    int pr = i / PCF, off = i - pr * PCF;
+    int hh = h0 - 1 + pr;
+    int col = (w0 - 1) * 3 + off;                 // float index inside the image row
+    float v = 0.f;
+    if ((unsigned)hh < (unsigned)H && (unsigned)col < (unsigned)(W * 3)) v = img[((long long)n * H + hh) * W * 3 + col];
+    patch[i] = v;
+  }
+  __syncthreads();
+  const int hy = h0 + wave;
   if (hy < H) {
 #pragma unroll
     for (int j = 0; j < TW / 16; ++j) {
@@ -2342,6 +2345,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
       }
     }
   }
+  }   // tiles
   if (stats) {
     // lanes with equal fq hold the same channels: fold the 16 pixel lanes, one partial row per wave, then per block
 #pragma unroll
@@ -2984,6 +2988,7 @@ extern "C" int mgd_stem_fwd(const float* image, const float* w, void* y, float* 
   MGD_REQUIRE(!stats || stats_replicas >= 1, "stem_fwd: stats_replicas");
   MGD_REQUIRE(N >= 1 && H >= 1 && W >= 1 && (long long)N * H * W * 3 < (1ll << 31), "stem_fwd: N=%d H=%d W=%d", N, H, W);
   long long grid = (long long)N * ((H + 3) / 4) * ((W + 63) / 64);
+  if (grid > 256 * 8) grid = 256 * 8;               // persistent blocks: the statistics leave once per block
   hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, image, w, (bf16_t*)y, stats,
                      stats_replicas > 0 ? stats_replicas : 1, N, H, W);
   MGD_CHECK_LAUNCH("stem_fwd");
