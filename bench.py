@@ -97,13 +97,13 @@ def cpu_baseline(size):
                       f"batch 1, {cores} threads, after a 128x128 warm-up step; {dt:.2f} s"}
 
 
-def pmc_traffic():
+def pmc_traffic(prefix="conv_gemm2_kernel<2, 2, 4, 4, 2"):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (collected in separate
     rocprofv3 --pmc passes of this same command; FETCH_SIZE x2 on gfx950 + WRITE_SIZE); (None, reason) if absent."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.txt")
     try:
         for line in open(path):
-            if line.startswith("conv_gemm2_kernel<2, 2, 4, 4, 2"):
+            if line.startswith(prefix):
                 return int(float(line.split("|")[-1]) * 1024 * 1024), "profiles/r01_pmc_traffic.txt (separate --pmc passes)"
     except OSError:
         pass
@@ -190,27 +190,37 @@ def main():
     ips = world * args.batch * args.steps / dt
     roof = None
     if prof:
-        fl = sum(p[2] for p in prof if p[3] == "gemm128")
-        ms = sum(p[0].elapsed_time(p[1]) for p in prof if p[3] == "gemm128")
-        n = sum(1 for p in prof if p[3] == "gemm128")
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # the forward launches run alone on the GPU (the weight gradients only overlap the backward pass)
-        ffl = sum(p[2] for p in prof if p[3] == "gemm128" and p[4] == "conv_fwd")
-        fms = sum(p[0].elapsed_time(p[1]) for p in prof if p[3] == "gemm128" and p[4] == "conv_fwd")
-        fn = sum(1 for p in prof if p[3] == "gemm128" and p[4] == "conv_fwd")
-        fach = ffl / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
-        traffic, tsrc = pmc_traffic()
-        roof = {"bound": "mfma", "kernel": "conv_gemm2_kernel<2,2,4,4,2> (128x128-tile bf16 MFMA gather-GEMM: 3x3/1x1 "
-                                           "conv forward + data gradient)", "achieved": round(ach, 2),
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": tsrc, "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
-                "event_steps": 1, "share_of_step_time": round(ms / (dt * 1e3 / args.steps), 3),
-                "note": "durations include CU sharing with conv_wgrad2_kernel, which runs concurrently on a side stream "
-                        "during the backward pass; forward_only = the same kernel's forward launches, which run alone",
-                "forward_only": {"achieved": round(fach, 2), "frac": round(fach / PEAK_BF16_TFLOPS, 4), "launches": fn,
-                                 "avg_launch_us": round(1e3 * fms / max(fn, 1), 2)},
-                "whole_step_conv_tflops": round(ips / world * 3 * FLOP_PER_IMAGE_FWD * (args.size / 608) ** 2 / 1e12, 1),
-                "algorithmic_flop_per_launch_avg": round(fl / max(n, 1) / 1e9, 2)}
+        names = {"gemm128": "conv_gemm2_kernel<2,2,4,4,2> (128x128-tile bf16 MFMA gather-GEMM, two barrier-synchronous "
+                            "blocks per CU: 3x3/1x1 conv forward + data gradient)",
+                 "gemm128pc": "conv_gemm6_kernel<2,2,4,4,3> (128x128-tile bf16 MFMA gather-GEMM, producer/consumer waves)",
+                 "wgrad128": "conv_wgrad2_kernel<2,2,4,4> (128x128-tile bf16 MFMA weight gradient, per-tap blocks, split-K)"}
+        pmc_keys = {"gemm128": "conv_gemm2_kernel<2, 2, 4, 4, 2", "gemm128pc": "conv_gemm6_kernel<2, 2, 4, 4, 3",
+                    "wgrad128": "conv_wgrad2_kernel<2, 2, 4, 4>"}
+        step_ms = dt * 1e3 / args.steps
+
+        def summarise(tag, only=None):
+            sel = [p for p in prof if p[3] == tag and (only is None or p[4] == only)]
+            fl = sum(p[2] for p in sel)
+            ms = sum(p[0].elapsed_time(p[1]) for p in sel)
+            n = len(sel)
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"achieved": round(ach, 2), "frac": round(ach / PEAK_BF16_TFLOPS, 4), "launches": n,
+                    "avg_launch_us": round(1e3 * ms / max(n, 1), 2), "share_of_step_time": round(ms / step_ms, 3),
+                    "algorithmic_flop_per_launch_avg": round(fl / max(n, 1) / 1e9, 2)}
+        per = {t: summarise(t) for t in names}
+        dom = max(per, key=lambda t: per[t]["share_of_step_time"])       # the kernel the step spends most time in
+        traffic, tsrc = pmc_traffic(pmc_keys[dom])
+        roof = {"bound": "mfma", "kernel": names[dom], "achieved": per[dom]["achieved"], "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": per[dom]["frac"], "traffic": traffic, "traffic_unit": "bytes/launch",
+                "traffic_source": tsrc, "launches": per[dom]["launches"], "avg_launch_us": per[dom]["avg_launch_us"],
+                "event_steps": 1, "share_of_step_time": per[dom]["share_of_step_time"],
+                "algorithmic_flop_per_launch_avg": per[dom]["algorithmic_flop_per_launch_avg"],
+                "note": "HIP events on the launch stream around every launch of the last timed step; the backward pass "
+                        "runs two streams, so backward launches share the CUs with kernels of the other stream; "
+                        "forward_only = the gather-GEMM's forward launches, which run alone",
+                "other_kernels": {names[t].split(" ")[0]: per[t] for t in names if t != dom},
+                "forward_only": summarise("gemm128", "conv_fwd"),
+                "whole_step_conv_tflops": round(ips / world * 3 * FLOP_PER_IMAGE_FWD * (args.size / 608) ** 2 / 1e12, 1)}
     out = {
         "metric": "images/sec (train step, 608x608, bs/GPU=16)", "value": round(ips, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),

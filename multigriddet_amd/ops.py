@@ -257,7 +257,15 @@ def conv_wgrad(x, dy, dw, k, s, splits=None):
     for i, (a, b) in enumerate(zip(dh, dwo)):
         d.dh[i], d.dw_off[i] = a, b
     d.splits = splits if splits is not None else wgrad_splits(N * Ho * Wo, Co, Ci, k * k)
+    if PROFILE is None:
+        L.check(L.load().mgd_conv_wgrad(C.byref(d), L.stream_ptr()), "conv_wgrad")
+        return dw
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()                      # on the stream the launch goes to (the weight-gradient side stream in the engine)
     L.check(L.load().mgd_conv_wgrad(C.byref(d), L.stream_ptr()), "conv_wgrad")
+    e1.record()
+    variant = "wgrad128" if (Co > 64 and Ci > 64) else ("wgrad_patch" if (k == 3 and Ci in (32, 64) and Wo >= 16) else "wgrad_small")
+    PROFILE.append((e0, e1, 2.0 * N * Ho * Wo * k * k * Ci * Co, variant, "conv_wgrad"))
     return dw
 
 
