@@ -75,6 +75,10 @@ typedef struct mgd_conv_desc {
   const float* bn_invstd;
   float* bn_sums;
   float bn_slope;
+  /* inference with BatchNorm folded into the conv (weights pre-scaled by gamma/sqrt(var+eps), `bias` = the BN shift):
+   * act_slope != 0 applies LeakyReLU(act_slope) to (acc + bias) before the optional `addend` (= the residual input),
+   * i.e. the whole DarknetConv2D_BN_Leaky (+ Add) of models/layers.py:88-95 in one launch.  bf16 output only. */
+  float act_slope;
 } mgd_conv_desc;
 
 int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream);

@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ("ntaps", C.c_int32), ("dh", C.c_int32 * 9), ("dw", C.c_int32 * 9),
         ("K_pad", C.c_int32), ("Co_pad", C.c_int32), ("dst_f32", C.c_int32), ("stats_replicas", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_mean", C.c_void_p),
-        ("bn_invstd", C.c_void_p), ("bn_sums", C.c_void_p), ("bn_slope", C.c_float),
+        ("bn_invstd", C.c_void_p), ("bn_sums", C.c_void_p), ("bn_slope", C.c_float), ("act_slope", C.c_float),
     ]
 
 

@@ -42,6 +42,7 @@ struct GemmArgs {
   const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
   float* bn_sums;
   float bn_slope;
+  float act_slope;   // != 0: LeakyReLU on (acc + bias) before the addend (BatchNorm-folded inference)
 };
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * ROWB + ((kc ^ (row & 7)) << 4); }
@@ -201,6 +202,10 @@ __global__ __launch_bounds__(256) void conv_gather_gemm_kernel(GemmArgs a) {
       int pl = (wp * NT + n) * 16 + fr;
       f32x4 v = acc[m][n];
       v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+      if (a.act_slope != 0.f) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * a.act_slope;
+      }
       if (a.dst_f32) {
         *(f32x4*)(smem + pl * EROW + cl * 4) = v;
       } else {
@@ -531,6 +536,10 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
       int pl = (wp * NT + n) * 16 + fr;
       f32x4 v = acc[m][n];
       v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+      if (a.act_slope != 0.f) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * a.act_slope;
+      }
       if (a.dst_f32) {
         *(f32x4*)(smem + pl * EROW + cl * 4) = v;
       } else {
@@ -704,6 +713,10 @@ struct GemmEpilogue {
         int pl = (wp * NT + n) * 16 + fr;
         f32x4 v = acc[m][n];
         v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+        if (a.act_slope != 0.f) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * a.act_slope;
+        }
         if (a.dst_f32) {
           *(f32x4*)(smem + pl * EROW + cl * 4) = v;
         } else {
@@ -1589,6 +1602,10 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm3_kernel(GemmArgs a) {
       int pl = (wp * NT + n) * 16 + fr;
       f32x4 v = acc[m][n];
       v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+      if (a.act_slope != 0.f) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * a.act_slope;
+      }
       if (a.dst_f32) {
         *(f32x4*)(smem + pl * EROW + cl * 4) = v;
       } else {
@@ -2809,6 +2826,8 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   a.stamps = nullptr;
   a.bn_y = (const bf16_t*)d->bn_y; a.bn_scale = d->bn_scale; a.bn_shift = d->bn_shift; a.bn_mean = d->bn_mean;
   a.bn_invstd = d->bn_invstd; a.bn_sums = d->bn_sums; a.bn_slope = d->bn_slope;
+  a.act_slope = d->act_slope;
+  MGD_REQUIRE(d->act_slope == 0.f || (!d->dst_f32 && !d->stats && !d->bn_y), "conv: act_slope is for bf16 inference output (no stats / fused reductions)");
   MGD_REQUIRE(!d->bn_y || (d->bn_scale && d->bn_shift && d->bn_mean && d->bn_invstd && d->bn_sums && d->stats_replicas >= 1),
               "conv: fused BN-backward reduction needs scale/shift/mean/invstd/sums and stats_replicas");
 
@@ -2832,7 +2851,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     static int patch = -1;
     if (patch < 0) { const char* e = getenv("MGD_PATCH"); patch = e ? atoi(e) : 1; }
     bool std9p = d->ntaps == 9 && d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 && d->Hd == d->Hg &&
-                 d->Wd == d->Wg && !d->dst_f32 && !d->bias && d->K_pad >= 9 * d->Ci &&
+                 d->Wd == d->Wg && !d->dst_f32 && d->K_pad >= 9 * d->Ci &&
                  (d->in_stride == 1 || d->in_stride == 2) && d->Hs == d->Hg * d->in_stride && d->Ws == d->Wg * d->in_stride;
     for (int t = 0; t < 9 && std9p; ++t) std9p = d->dh[t] == t / 3 - 1 && d->dw[t] == t % 3 - 1;
     if (variant == 3 && patch && std9p && d->Ci == 32 && d->Co == 64 && d->Co_pad == 64) {

@@ -260,10 +260,46 @@ class Network:
             return False           # Keras: trainable=False puts BatchNormalization in inference mode
         return True
 
+    # ------------------------------------------------------------------ BatchNorm-folded inference
+    def fold_bn(self, on=True):
+        """Inference with every BatchNorm folded into its conv: weights pre-scaled by gamma / sqrt(moving_var + eps), the BN
+        shift as bias, LeakyReLU and the residual add in the conv epilogue - one launch per DarknetConv2D_BN_Leaky
+        (models/layers.py:88-95) instead of conv + BN/activation pass.  Opt-in (the unfolded path is the one the parity
+        tests pin; folding rounds the scaled weights to bf16 instead of rounding y).  Call again after the weights change."""
+        self.folded = bool(on)
+        if not on:
+            return
+        if getattr(self, "_fold_imgs", None) is None:
+            self._fold_imgs = {cv.idx: torch.zeros_like(cv.pk.fwd) for cv in self.layers if cv.bn and cv.pk is not None}
+            self._fold_w = torch.zeros_like(self.params)
+            self._fold_shift = {}
+        fw = self._fold_w
+        fw.copy_(self.params)
+        for cv in self.layers:
+            if not cv.bn:
+                continue
+            sc = cv.gamma / torch.sqrt(cv.mv + ops.BN_EPS)
+            self._fold_shift[cv.idx] = (cv.beta - cv.mm * sc).contiguous()
+            n = cv.cout * cv.T * cv.cin
+            fw[cv.off_w:cv.off_w + n].view(cv.cout, -1).mul_(sc[:, None])
+        jobs = []
+        for cv in self.layers:
+            if cv.bn and cv.pk is not None:
+                n = cv.cout * cv.T * cv.cin
+                jobs.append((cv, fw[cv.off_w:cv.off_w + n].view(cv.cout, cv.T, cv.cin)))
+        for cv, w in jobs:                      # one-off: pack the scaled masters into the folded forward images
+            keep = cv.pk.fwd
+            cv.pk.fwd = self._fold_imgs[cv.idx]
+            cv.pk.refresh_fwd(w)
+            cv.pk.fwd = keep
+
     def _conv_bn_act(self, A, i, x, residual=None):
         cv = self.layers[i]
         tr = self._bn_training(cv)
         y = A["y"][i]
+        if getattr(self, "folded", False) and not tr and cv.role != "stem":
+            return ops.conv_fwd(x, cv.pk, out=A["a"][i], bias=self._fold_shift[cv.idx], act_slope=ops.LEAKY_SLOPE,
+                                addend=residual, wimg=self._fold_imgs[cv.idx])
         if cv.role == "stem":       # matrix-core stem straight from the fp32 image (no im2col image in the forward pass)
             ops.stem_fwd(x, cv.w, out=y, stats=cv.stats if tr else None)
         else:

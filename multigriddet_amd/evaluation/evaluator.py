@@ -47,6 +47,8 @@ class MultiGridEvaluator:
         self.class_names = load_classes(classes_path)
         self.anchors = load_anchors(self.model_config["model"]["preset"]["anchors_path"])
         self.model = build_model_for_inference(self.full_config, weights_path)
+        if self.config.get("fold_bn", False):      # opt-in (not a reference key): BatchNorm folded into the convs
+            self.model.fold_bn(True)
 
     def _load_annotations(self, annotation_file: str) -> List[Dict]:
         annotations = []

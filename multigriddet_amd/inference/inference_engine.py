@@ -40,6 +40,8 @@ class MultiGridInference:
         self.input_shape = tuple(self.model_config["model"]["preset"].get("input_shape", [608, 608, 3])[:2])
         self.decoder = MultiGridDecoder(self.anchors, len(self.class_names), self.input_shape, rescore_confidence=True)
         self.model = build_model_for_inference(self.full_config, weights_path)
+        if self.config.get("fold_bn", False):      # opt-in (not a reference key): BatchNorm folded into the convs
+            self.model.fold_bn(True)
 
     def _detect_cfg(self):
         d = self.config.get("detection", {})

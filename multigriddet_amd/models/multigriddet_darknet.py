@@ -89,6 +89,12 @@ class MultiGridDetModel:
         self.net.training = prev
         return outs
 
+    def fold_bn(self, on=True):
+        """Opt-in inference mode: every BatchNorm folded into its conv (one launch per conv block); see
+        engine.Network.fold_bn.  Call after loading weights."""
+        self.net.fold_bn(on)
+        return self
+
     def predict(self, x, verbose=0, batch_size=None):
         return [o.cpu().numpy() for o in self(x, training=False)]
 

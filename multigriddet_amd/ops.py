@@ -90,6 +90,12 @@ class PackedConv:
                         self.dgrad.append((torch.zeros(cp, kp, dtype=torch.bfloat16, device=device), kp, cp,
                                            [t[2] for t in tp], (ph, pw, tp)))
 
+    def refresh_fwd(self, w):
+        """w: fp32 [Co, T, Ci] -> rewrite the forward image only."""
+        src = (C.c_int32 * 9)(*range(self.T), *([0] * (9 - self.T)))
+        L.check(L.load().mgd_pack_weights(L.ptr(w), L.ptr(self.fwd), self.co, self.T, self.ci_master, 0, self.T, src,
+                                          self.fwd_copad, self.fwd_kpad, L.stream_ptr()), "pack fwd")
+
     def refresh(self, w):
         """w: fp32 [Co, T, Ci] master weights -> rewrite the packed images."""
         lib = L.load()
@@ -143,8 +149,9 @@ def stem_im2col(image, out=None):
 
 
 def _desc(src, wpk, dst, N, Hs, Ws, Ci, Hg, Wg, Hd, Wd, Co, in_stride, out_stride, off, dh, dw, K_pad, Co_pad,
-          bias=None, addend=None, stats=None, dst_f32=False, bnred=None):
+          bias=None, addend=None, stats=None, dst_f32=False, bnred=None, act_slope=0.0):
     d = L.ConvDesc()
+    d.act_slope = act_slope
     d.src, d.wpk, d.dst = src.data_ptr(), wpk.data_ptr(), dst.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.addend = addend.data_ptr() if addend is not None else None
@@ -164,16 +171,17 @@ def _desc(src, wpk, dst, N, Hs, Ws, Ci, Hg, Wg, Hd, Wd, Co, in_stride, out_strid
     return d
 
 
-def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False):
-    """x: bf16 [N,H,W,Ci] -> [N,Ho,Wo,Co]; 'same' for stride 1, top/left pad + 'valid' for stride 2."""
+def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False, act_slope=0.0, addend=None, wimg=None):
+    """x: bf16 [N,H,W,Ci] -> [N,Ho,Wo,Co]; 'same' for stride 1, top/left pad + 'valid' for stride 2.
+    act_slope / addend / wimg: BatchNorm-folded inference - LeakyReLU(acc + bias) + residual from pre-scaled weights."""
     N, H, W, Ci = x.shape
     assert Ci == pk.ci and x.dtype == torch.bfloat16
     Ho, Wo = (H // 2, W // 2) if pk.s == 2 else (H, W)
     if out is None:
         out = torch.empty(N, Ho, Wo, pk.co, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     dh, dw = taps_fwd(pk.k)
-    d = _desc(x, pk.fwd, out, N, H, W, Ci, Ho, Wo, Ho, Wo, pk.co, pk.s, 1, (0, 0), dh, dw, pk.fwd_kpad,
-              pk.fwd_copad, bias=bias, stats=stats, dst_f32=out_f32)
+    d = _desc(x, pk.fwd if wimg is None else wimg, out, N, H, W, Ci, Ho, Wo, Ho, Wo, pk.co, pk.s, 1, (0, 0), dh, dw,
+              pk.fwd_kpad, pk.fwd_copad, bias=bias, stats=stats, dst_f32=out_f32, act_slope=act_slope, addend=addend)
     _launch_gemm(d, "conv_fwd")
     return out
 

@@ -258,3 +258,42 @@ def test_multiscale_steps_share_one_network():
     torch.cuda.synchronize()
     assert ts.step_count == len(sizes)
     assert last[320] < first[320]            # the shared weights keep training across resolutions
+
+
+@pytest.mark.gpu
+def test_fold_bn_inference_matches_unfolded():
+    """Network.fold_bn(): BatchNorm folded into the convs (scaled weights, shift as bias, LeakyReLU + residual in the conv
+    epilogue) against the conv + BN/activation path, on non-trivial moving statistics.  bf16 storage on both sides, the
+    folded path rounds the scaled weights instead of y, hence a relative-L2 tolerance (the statistics are damped as in the
+    wiring test so that 69 layers do not amplify the rounding difference)."""
+    import torch
+    from multigriddet_amd.engine import Network
+    dev = torch.device("cuda:0")
+    net = Network(80, 3, dev, seed=3)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for cv in net.layers:
+        if cv.bn:
+            C = cv.cout
+            cv.gamma.copy_((torch.rand(C, generator=g) * 0.5 + 0.75).to(dev))
+            cv.beta.copy_((torch.randn(C, generator=g) * 0.1).to(dev))
+            cv.mm.copy_((torch.randn(C, generator=g) * 0.05).to(dev))
+            cv.mv.copy_((torch.rand(C, generator=g) * 1.0 + 3.5).to(dev))      # damped: per-layer gain ~0.5
+    net.refresh_packed()
+    net.training = False
+    x = torch.rand(2, 128, 160, 3, generator=g).to(dev)
+    ref = [o.clone() for o in net.forward(x)]
+    acts_ref = [net._last["a"][i].clone() for i in range(8)]
+    net.fold_bn(True)
+    out = [o.clone() for o in net.forward(x)]
+    acts = [net._last["a"][i].clone() for i in range(8)]
+    net.fold_bn(False)
+    again = net.forward(x)
+    torch.cuda.synchronize()
+    for i, (ar, af) in enumerate(zip(acts_ref, acts)):          # layer by layer at the start of the network
+        rel = ((af.float() - ar.float()).norm() / ar.float().norm()).item()
+        assert rel < 1.5e-2, (i, rel)
+    for r, o, a2 in zip(ref, out, again):
+        assert o.shape == r.shape and torch.isfinite(o).all()
+        rel = ((o - r).norm() / r.norm()).item()
+        assert rel < 5e-2, rel
+        assert torch.equal(a2, r)              # switching it off restores the pinned path bit for bit

@@ -214,6 +214,26 @@ def test_bn_act_fwd_bwd(dev, C, P, res):
     assert e <= 0.02 * yr.grad.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("N,H,W,Ci,Co,k,s", [(2, 40, 36, 32, 64, 3, 1), (2, 48, 32, 32, 64, 3, 2), (2, 20, 20, 64, 128, 3, 1),
+                                             (4, 64, 64, 128, 256, 3, 1), (3, 19, 19, 256, 128, 1, 1)])
+def test_conv_bias_leaky_residual_epilogue(dev, N, H, W, Ci, Co, k, s):
+    """BatchNorm-folded inference epilogue: LeakyReLU(conv + bias) + residual in the conv launch (act_slope / addend)."""
+    from multigriddet_amd import ops
+    g = torch.Generator().manual_seed(4242 + Ci + Co + s)
+    x = bf(torch.randn(N, H, W, Ci, generator=g))
+    w = torch.randn(Co, k * k, Ci, generator=g) / (k * (Ci ** 0.5))
+    bias = torch.randn(Co, generator=g) * 0.5
+    pk = ops.PackedConv(Co, Ci, k, s, dev)
+    pk.refresh(w.to(dev))
+    y_ref = _ref_conv(x, w, k, s) + bias
+    res = bf(torch.randn(*y_ref.shape, generator=g))
+    ref = torch.where(y_ref > 0, y_ref, 0.1 * y_ref) + res.float()
+    out = ops.conv_fwd(x.to(dev), pk, bias=bias.to(dev), act_slope=0.1, addend=res.to(dev))
+    torch.cuda.synchronize()
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err <= 0.02 * ref.abs().max().item() + 1e-3, err
+
+
 @pytest.mark.parametrize("N,H,W,Ci,Co,k,s", [(2, 20, 20, 64, 128, 3, 1), (2, 24, 24, 32, 64, 3, 2), (3, 19, 19, 256, 128, 1, 1),
                                              (2, 44, 36, 32, 64, 3, 1)])      # patch-form data gradient (64 -> 32)
 def test_dgrad_fused_bn_reduction(dev, N, H, W, Ci, Co, k, s):
