@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
   constexpr int RING = NS * STAGE;
   constexpr int EPI_MAX = BMP * (BNC * 4 + 16);
   constexpr int AUX = RING > EPI_MAX ? RING : EPI_MAX;
-  static_assert(NS == 3, "3-stage ring");
+  static_assert(NS == 3 || NS == 4, "3- or 4-stage ring");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   long long* row_dst = (long long*)(smem + AUX);
@@ -1093,13 +1093,18 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
       cch += BK;
       while (cch >= a.Ci) { cch -= a.Ci; ++tap; }
     };
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    int islot = 2;
+    // look-ahead LA = NS - 1 stages: after the barrier of K-step s the slot of stage s-1 is free and stage s+LA goes
+    // into it, so a stage has LA-1 whole K-steps to land before the loaders wait for it
+    constexpr int LA = NS - 1;
+    int islot = 0;
+#pragma unroll
+    for (int p = 0; p < LA; ++p)
+      if (p < nk) { issue(p, islot); if (++islot == NS) islot = 0; }
     for (int s = 0; s < nk; ++s) {
-      if (s + 1 < nk) wait_vmcnt<LPS>(); else wait_vmcnt<0>();     // stage s has landed (s+1 may be in flight)
+      const int younger = min(LA - 1, nk - 1 - s);                 // stages that may stay in flight behind stage s
+      if (younger >= 2) wait_vmcnt<2 * LPS>(); else if (younger == 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();                                // consumers: stage s is yours, stage s-1's slot is free
-      if (s + 2 < nk) { issue(s + 2, islot); if (++islot == NS) islot = 0; }
+      if (s + LA < nk) { issue(s + LA, islot); if (++islot == NS) islot = 0; }
     }
     __syncthreads();
     return;
@@ -2872,7 +2877,9 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   const long long nblk128 = (long long)(d->Co_pad / 128) * cdiv(a.M, 128);
   if (d->Co_pad % 128 == 0 && nk >= 4 && !d->dst_f32 &&
       (variant == 9 || (variant == 3 && pc && (nblk128 <= 256 || (nblk128 <= 768 && nk >= 32))))) {
-    launch_gemm6<2, 2, 4, 4, 3>(a, st);
+    static int ns6 = -1;
+    if (ns6 < 0) { const char* e = getenv("MGD_PC_STAGES"); ns6 = e ? atoi(e) : 3; }
+    if (ns6 == 4) launch_gemm6<2, 2, 4, 4, 4>(a, st); else launch_gemm6<2, 2, 4, 4, 3>(a, st);
     MGD_CHECK_LAUNCH("conv_gather_gemm(producer/consumer)");
     return MGD_OK;
   }
