@@ -128,6 +128,13 @@ int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream);
 int mgd_stem_fwd(const float* image, const float* w, void* y, float* stats, int stats_replicas, int N, int H,
                  int W, void* stream);
 int mgd_stem_wgrad(const float* image, const void* dy, float* dw, int N, int H, int W, void* stream);
+/* mgd_stem_wgrad with the stem's BatchNorm + LeakyReLU backward (layers.py:94-95) applied on the fly: takes da (gradient
+ * wrt the activated stem output) and y (raw stem output) instead of dy, the per-channel scale/shift/mean/invstd of the
+ * forward pass and the replicated sums [replicas][2][32] of (dyh, dyh*yhat) that the producer of da accumulated;
+ * adds dbeta / dgamma (+=).  dy itself is never written. */
+int mgd_stem_wgrad_bn(const float* image, const void* da, const void* y, const float* scale, const float* shift,
+                      const float* save_mean, const float* save_invstd, const float* sums, int replicas, float* dgamma,
+                      float* dbeta, float slope, float* dw, int N, int H, int W, void* stream);
 
 /* Pack fp32 master weights W[Co][T][Ci] (OHWI) into a bf16 gather-GEMM image.
  * out[r][t'*Cin' + c] = transpose ? W[c][src_tap[t']][r] : W[r][src_tap[t']][c], zero padded to

@@ -124,6 +124,7 @@ class Network:
         # leave idle.  Needs one dy buffer per layer (no scratch reuse while a side-stream wgrad may read it).
         self.overlap_wgrad = True
         self.wg_stream = torch.cuda.Stream(device=dev)
+        self.fuse_stem_bn = True        # stem: BN backward applied inside the weight-gradient kernel (dy0 never written)
         self.fuse_bn_reduce = True      # BN-backward reduction inside the dgrad epilogue that produces `da` (A/B: 0.9 ms/step faster)
         self._arenas = {}
         self.reset_parameters(seed)
@@ -492,13 +493,20 @@ class Network:
             if on_layer_done:
                 on_layer_done(ld)
             i -= 1
-        dy0 = self._bwd_bn(A, 0, g)
-        ev = torch.cuda.Event()
-        ev.record()
-        side = self.wg_stream if self.overlap_wgrad else torch.cuda.current_stream()
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            ops.stem_wgrad(A["image"], dy0, Lr[0].dw)        # matrix cores, straight from the fp32 image
+        c0 = Lr[0]
+        if self.fuse_stem_bn and 0 in A["reduced"] and self._bn_training(c0):
+            # the sums are already there (fused into layer 1's input gradient): apply BN backward inside the weight
+            # gradient, dy0 never touches HBM
+            ops.stem_wgrad_bn(A["image"], g, A["y"][0], c0.scale, c0.shift, c0.smean, c0.sinv, c0.sums, c0.dgamma,
+                              c0.dbeta, c0.dw)
+        else:
+            dy0 = self._bwd_bn(A, 0, g)
+            ev = torch.cuda.Event()
+            ev.record()
+            side = self.wg_stream if self.overlap_wgrad else torch.cuda.current_stream()
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                ops.stem_wgrad(A["image"], dy0, c0.dw)       # matrix cores, straight from the fp32 image
         self._join_wgrad()
         if on_layer_done:
             on_layer_done(0)

@@ -292,6 +292,16 @@ def stem_wgrad(image, dy, dw):
     return dw
 
 
+def stem_wgrad_bn(image, da, y, scale, shift, smean, sinv, sums, dgamma, dbeta, dw):
+    """Stem weight gradient with the stem's BN + LeakyReLU backward fused in (dy is never materialised); `sums` must hold
+    the reduction the producer of `da` accumulated (conv_dgrad(..., bnred=...))."""
+    N, H, W, _ = image.shape
+    L.check(L.load().mgd_stem_wgrad_bn(L.ptr(image), L.ptr(da), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(smean),
+                                       L.ptr(sinv), L.ptr(sums), STATS_REPLICAS, L.ptr(dgamma), L.ptr(dbeta),
+                                       C.c_float(LEAKY_SLOPE), L.ptr(dw), N, H, W, L.stream_ptr()), "stem_wgrad_bn")
+    return dw
+
+
 # ------------------------------------------------------------------------------------------- BN / act
 def bn_finalize(stats, count, gamma, beta, mm, mv, scale, shift, smean, sinv, training=True):
     Cn = gamma.numel()

@@ -157,6 +157,42 @@ def test_stem(dev):
     np.testing.assert_allclose(dw.cpu().numpy() - 0.5, wr2.grad.numpy(), rtol=1e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 40, 48), (1, 37, 70), (3, 64, 130)])
+def test_stem_wgrad_fused_bn_backward(dev, N, H, W):
+    """mgd_stem_wgrad_bn (BN + LeakyReLU backward applied inside the weight gradient) against the two-kernel path
+    bn_act_bwd -> stem_wgrad it replaces: same sums, same bf16 rounding of dy, so dw / dgamma / dbeta agree to
+    accumulation order."""
+    from multigriddet_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + H + W)
+    img = torch.rand(N, H, W, 3, generator=g).to(dev)
+    y = bf(torch.randn(N, H, W, 32, generator=g) * 1.5 + 0.3).to(dev)
+    da = bf(torch.randn(N, H, W, 32, generator=g)).to(dev)
+    gamma = (torch.rand(32, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(32, generator=g) * 0.2).to(dev)
+    P = N * H * W
+    stats = torch.zeros(ops.STATS_REPLICAS, 2, 32, device=dev)
+    yb = y.float().view(-1, 32)
+    stats[0, 0] = yb.sum(0)
+    stats[0, 1] = (yb * yb).sum(0)
+    mm, mv = torch.zeros(32, device=dev), torch.ones(32, device=dev)
+    scale, shift, smean, sinv = (torch.empty(32, device=dev) for _ in range(4))
+    ops.bn_finalize(stats, float(P), gamma, beta, mm, mv, scale, shift, smean, sinv)
+    sums = torch.zeros((ops.STATS_REPLICAS + 1) * 2 * 32, device=dev)
+    dgam, dbet = torch.zeros(32, device=dev), torch.zeros(32, device=dev)
+    dy = torch.empty(N, H, W, 32, dtype=torch.bfloat16, device=dev)
+    ops.bn_act_bwd(da, y, scale, shift, smean, sinv, sums, dgam, dbet, dy)       # fills sums, dy
+    dw_ref = torch.zeros(32, 9, 3, device=dev)
+    ops.stem_wgrad(img, dy, dw_ref)
+    dgam2, dbet2 = torch.zeros(32, device=dev), torch.zeros(32, device=dev)
+    dw = torch.full((32, 9, 3), 0.25, device=dev)                                # accumulates (+=)
+    ops.stem_wgrad_bn(img, da, y, scale, shift, smean, sinv, sums, dgam2, dbet2, dw)
+    torch.cuda.synchronize()
+    ref = dw_ref.cpu().numpy()
+    np.testing.assert_allclose(dw.cpu().numpy() - 0.25, ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()) + 1e-5)
+    np.testing.assert_allclose(dgam2.cpu().numpy(), dgam.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dbet2.cpu().numpy(), dbet.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("C,P,res", [(32, 5000, False), (64, 3000, True), (256, 777, True), (704, 361, False),
                                      (1024, 1444, True)])
 def test_bn_act_fwd_bwd(dev, C, P, res):

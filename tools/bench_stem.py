@@ -22,5 +22,12 @@ dw = torch.zeros(32, 27, device=dev)
 t_wd = timeit(lambda: ops.stem_wgrad(img, dy, dw))
 dw2 = torch.zeros(32, 1, 32, device=dev)
 t_wg = timeit(lambda: ops.conv_wgrad(col, dy, dw2, 1, 1))
+da = torch.randn(B, S, S, 32, device=dev).to(torch.bfloat16)
+sc, sh, mu, iv = (torch.rand(32, device=dev) + 0.5 for _ in range(4))
+sums = torch.zeros((ops.STATS_REPLICAS + 1) * 2 * 32, device=dev)
+dg, db = torch.zeros(32, device=dev), torch.zeros(32, device=dev)
+t_ap = timeit(lambda: ops.bn_act_bwd(da, y, sc, sh, mu, iv, sums, dg, db, dy, reduced=True))
+t_fu = timeit(lambda: ops.stem_wgrad_bn(img, da, y, sc, sh, mu, iv, sums, dg, db, dw))
+print(f"wgrad + BN backward: apply {t_ap:.1f} + wgrad {t_wd:.1f} = {t_ap + t_wd:.1f} us | fused {t_fu:.1f} us")
 print(f"forward: direct {t_direct:.1f} us | im2col {t_col:.1f} + gemm {t_gemm:.1f} = {t_col + t_gemm:.1f} us")
 print(f"wgrad  : direct {t_wd:.1f} us | gemm on the im2col image {t_wg:.1f} us")
