@@ -2296,16 +2296,20 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   __shared__ float red[4][2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tilesW = (W + TW - 1) / TW, tilesH = (H + TH - 1) / TH;
-  // A fragments: lane (fr = cout within the 16-row tile, fq = k group) holds w[m*16 + fr][fq*8 .. +7]
+  // A fragments: lane (fr = row of the 16-row tile, fq = k group) holds w[chan(m, fr)][fq*8 .. +7].  The rows are
+  // permuted, chan(m, row) = (row / 4) * 8 + m * 4 + row % 4, so that the accumulators of a lane (rows fq*4 .. +3 of
+  // both tiles) are the eight consecutive channels fq*8 .. +7: one 16-byte store per pixel and lane, a wave writes
+  // 16 pixels x 64 B contiguously.
   const int fr = lane & 15, fq = lane >> 4;
   bf16x8 wf[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     float t[8];
+    const int co = (fr >> 2) * 8 + m * 4 + (fr & 3);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       int k = fq * 8 + i;
-      t[i] = k < 27 ? w[(m * 16 + fr) * 27 + k] : 0.f;
+      t[i] = k < 27 ? w[co * 27 + k] : 0.f;
     }
     wf[m] = __builtin_bit_cast(bf16x8, pack8(t));
   }
@@ -2322,6 +2326,26 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
   const int ntiles = N * tilesH * tilesW;
+  // the next tile's patch is fetched into registers while the current one is computed and stored
+  constexpr int NPV = (PR * PCF + 255) / 256;
+  float pv[NPV];
+  auto fetch = [&](int tile) {
+    int b = tile;
+    const int tw = b % tilesW; b /= tilesW;
+    const int th = b % tilesH;
+    const int n = b / tilesH;
+#pragma unroll
+    for (int u = 0; u < NPV; ++u) {
+      int i = tid + u * 256;
+      int pr = i / PCF, off = i - pr * PCF;
+      int hh = th * TH - 1 + pr;
+      int col = (tw * TW - 1) * 3 + off;            // float index inside the image row
+      pv[u] = 0.f;
+      if (i < PR * PCF && (unsigned)hh < (unsigned)H && (unsigned)col < (unsigned)(W * 3))
+        pv[u] = img[((long long)n * H + hh) * W * 3 + col];
+    }
+  };
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   int b = tile;
   const int tw = b % tilesW; b /= tilesW;
@@ -2329,15 +2353,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   const int n = b / tilesH;
   const int h0 = th * TH, w0 = tw * TW;
   __syncthreads();                                  // previous tile's patch reads are done
-  for (int i = tid; i < PR * PCF; i += 256) {
-    int pr = i / PCF, off = i - pr * PCF;
-    int hh = h0 - 1 + pr;
-    int col = (w0 - 1) * 3 + off;                 // float index inside the image row
-    float v = 0.f;
-    if ((unsigned)hh < (unsigned)H && (unsigned)col < (unsigned)(W * 3)) v = img[((long long)n * H + hh) * W * 3 + col];
-    patch[i] = v;
+#pragma unroll
+  for (int u = 0; u < NPV; ++u) {
+    int i = tid + u * 256;
+    if (i < PR * PCF) patch[i] = pv[u];
   }
   __syncthreads();
+  if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
   const int hy = h0 + wave;
   if (hy < H) {
 #pragma unroll
@@ -2350,14 +2372,15 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
       bf16x8 xf = __builtin_bit_cast(bf16x8, pack8(t));
       const bool ok = w0 + px < W;
       bf16_t* yr = y + (((long long)n * H + hy) * W + w0 + px) * 32;
+      uint4 st;
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         uint2 pk;
         pk.x = pack2bf(acc[0], acc[1]);
         pk.y = pack2bf(acc[2], acc[3]);
+        if (m == 0) { st.x = pk.x; st.y = pk.y; } else { st.z = pk.x; st.w = pk.y; }
         if (ok) {
-          *(uint2*)(yr + m * 16 + fq * 4) = pk;
           float v0 = __uint_as_float(pk.x << 16), v1 = __uint_as_float(pk.x & 0xffff0000u);
           float v2 = __uint_as_float(pk.y << 16), v3 = __uint_as_float(pk.y & 0xffff0000u);
           s1[m][0] += v0; s1[m][1] += v1; s1[m][2] += v2; s1[m][3] += v3;
@@ -2365,6 +2388,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
           s2[m][2] = fmaf(v2, v2, s2[m][2]); s2[m][3] = fmaf(v3, v3, s2[m][3]);
         }
       }
+      if (ok) *(uint4*)(yr + fq * 8) = st;
     }
   }
   }   // tiles
@@ -2378,8 +2402,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
         if (fr == 0) {
-          red[wave][0][m * 16 + fq * 4 + r] = x1;
-          red[wave][1][m * 16 + fq * 4 + r] = x2;
+          red[wave][0][fq * 8 + m * 4 + r] = x1;
+          red[wave][1][fq * 8 + m * 4 + r] = x2;
         }
       }
     __syncthreads();
