@@ -85,14 +85,48 @@ class MultiGridDetModel:
         prev = self.net.training
         self.net.training = bool(training)
         xt = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
-        outs = self.net.forward(xt.to(self.net.device, torch.float32).contiguous())
-        self.net.training = prev
-        return outs
+        xt = xt.to(self.net.device, torch.float32).contiguous()
+        try:
+            if not training and getattr(self, "_use_graph", False):
+                return self._forward_graph(xt)
+            return self.net.forward(xt)
+        finally:
+            self.net.training = prev
+
+    def enable_graph(self, on=True):
+        """Opt-in: inference forwards are replayed from a captured hipGraph, one per input shape (the ~130 launches of
+        a forward pass become one; matters for small batches, where the pass is launch-bound).  The returned head
+        tensors are static buffers, overwritten by the next call - as in the eager path.  Weights may change in
+        place (load_weights); call fold_bn / enable_graph again after anything that re-allocates."""
+        self._use_graph = bool(on)
+        self._graphs = {}
+        return self
+
+    def _forward_graph(self, xt):
+        key = (tuple(xt.shape), bool(getattr(self.net, "folded", False)))
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._graphs[key] = {"eager": 0, "graph": None}
+        if st["graph"] is None:
+            if st["eager"] < 2:                       # allocations (arena, workspaces) happen outside the capture
+                st["eager"] += 1
+                return self.net.forward(xt)
+            st["x"] = xt.clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["outs"] = self.net.forward(st["x"])
+            st["graph"] = g
+        if xt.data_ptr() != st["x"].data_ptr():
+            st["x"].copy_(xt)
+        st["graph"].replay()
+        return st["outs"]
 
     def fold_bn(self, on=True):
         """Opt-in inference mode: every BatchNorm folded into its conv (one launch per conv block); see
         engine.Network.fold_bn.  Call after loading weights."""
         self.net.fold_bn(on)
+        self._graphs = {}
         return self
 
     def predict(self, x, verbose=0, batch_size=None):

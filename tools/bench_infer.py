@@ -18,11 +18,14 @@ ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--method", default="diou")
 ap.add_argument("--confidence", type=float, default=0.1)
 ap.add_argument("--fold-bn", action="store_true", help="BatchNorm folded into the convs (one launch per conv block)")
+ap.add_argument("--graph", action="store_true", help="replay the forward pass from a captured hipGraph")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 model, _ = build_multigriddet_darknet(input_shape=(args.size, args.size, 3), num_classes=80)
 if args.fold_bn:
     model.fold_bn(True)
+if args.graph:
+    model.enable_graph(True)
 dec = MultiGridDecoder(bench.coco_anchors(), 80, (args.size, args.size))
 img = torch.from_numpy(np.random.default_rng(0).random((args.batch, args.size, args.size, 3), dtype=np.float32)).to(dev)
 shapes = [(480, 640)] * args.batch
@@ -48,6 +51,6 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(json.dumps({"metric": "inference images/sec incl. decode+NMS", "value": round(args.batch * args.steps / dt, 1),
                   "unit": "images/sec", "batch": args.batch, "size": args.size, "nms": args.method,
-                  "fold_bn": bool(args.fold_bn), "ms_per_batch": round(1e3 * dt / args.steps, 3), "last_forward_ms": round(e0.elapsed_time(e1), 3),
+                  "fold_bn": bool(args.fold_bn), "graph": bool(args.graph), "ms_per_batch": round(1e3 * dt / args.steps, 3), "last_forward_ms": round(e0.elapsed_time(e1), 3),
                   "last_decode_nms_ms": round(e1.elapsed_time(e2), 3), "detections_last_batch": int(r[3].sum()),
                   "dtype": "bf16", "data": "synthetic, random-init weights"}))
