@@ -2062,6 +2062,7 @@ struct Wgrad3Args {
   int N, Hs, Ws, Ci, Hg, Wg, Co;
   int s, R, TW, PC, PP;     // stride, output tile, patch columns, patch pixels
   int tilesH, tilesW, ntiles, per_split, tilesCo;
+  int tilesCi;              // ROW form: Ci slices of BCI channels
   int nst;                  // ring stages (2..6), one block per CU
   int dbg;                  // diagnostics: 16 = no atomics
   int stage;                // bytes per ring stage
@@ -2085,8 +2086,17 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 
 // PPW = patch pieces (1 KiB LDS-DMA wave-instructions) per wave and stage: every wave issues exactly
 // OPW + PPW loads per stage, so the counted vmcnt waits are wave-uniform.
-template <int MT, int NT, int PPW>
+// ROW = true: the form for Ci >= 128 (stride 1).  Nine taps of a 128 x 128 slice do not fit the register file, so a
+// block owns the THREE taps of one kernel row (dh = block index) of a [BCO co] x [BCI ci] slice: the patch is the R
+// pixel rows h0 + dh - 1 .. of the tile with one halo column either side, read at the three column shifts.  Against
+// the per-tap blocks of v2 that is one staged dy tile + one input patch (40 KB) per 3 x 128 x 128 x 64 MACs instead
+// of per 128 x 128 x 64, and a third of the barriers.  Measured (MGD_WGRAD_ROW=1, tools/bench_wgrad_row.py): the K-loop
+// is 22 % faster than v2's (128->256 at 76x76: 88 us against ~113), but a block's partial result is three tiles, so the
+// fp32-atomic epilogue moves 3x the bytes (49 MB at the memory-side atomic rate of ~1.2 TB/s = 42 us, a third of the
+// launch) and the total ties with v2: 130 / 126 / 141 us against 127 / 122 / 148 us.  Hence opt-in.
+template <int MT, int NT, int PPW, bool ROW = false>
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
+  constexpr int NTAP = ROW ? 3 : 9;
   constexpr int BCO = 2 * MT * 16, BCI = 2 * NT * 16;
   constexpr int RBO = BCO * 2;                 // dy-tile row bytes
   constexpr int PB = BCI * 2, PBP = PB + 32;   // patch pixel bytes, padded pitch
@@ -2098,7 +2108,11 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave >> 1, wi = wave & 1;
-  const int tco = blockIdx.x % a.tilesCo, split = blockIdx.x / a.tilesCo;
+  int bx = blockIdx.x;
+  const int tco = bx % a.tilesCo; bx /= a.tilesCo;
+  int ci0 = 0, dh = 0;
+  if (ROW) { ci0 = (bx % a.tilesCi) * BCI; bx /= a.tilesCi; dh = bx % 3; bx /= 3; }
+  const int split = bx;
   const int co0 = tco * BCO;
   const int kt0 = split * a.per_split;
   const int kt1 = min(a.ntiles, kt0 + a.per_split);
@@ -2111,7 +2125,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
   for (int i = 0; i < OPW; ++i) {
     int p = (i * 4 + wave) * ORPI + lane / (RBO / 16);
     int o_s = lane % (RBO / 16);
-    int ch = (((o_s >> 1) ^ tr_swz(p, RBO / 32)) << 1) | (o_s & 1);
+    int ch = (((o_s >> 1) ^ (ROW ? (p & (RBO / 32 - 1)) : tr_swz(p, RBO / 32))) << 1) | (o_s & 1);
     int r = p / a.TW, c = p - r * a.TW;
     bool ok = r < a.R && co0 + ch * 8 < a.Co;
     dy_off[i] = (unsigned)((((long long)r * a.Wg + c) * a.Co + co0 + ch * 8) * 2);
@@ -2125,7 +2139,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
     int pp = bo / PBP, chunk = (bo - pp * PBP) >> 4;
     int pr = pp / a.PC, pc = pp - pr * a.PC;
     bool ok = pp < a.PP && chunk < PB / 16;
-    p_off[j] = (unsigned)((((long long)pr * a.Ws + pc) * a.Ci + chunk * 8) * 2);
+    p_off[j] = (unsigned)((((long long)pr * a.Ws + pc) * a.Ci + ci0 + chunk * 8) * 2);
     p_rc[j] = ok ? ((unsigned)pr << 16 | (unsigned)pc) : 0x7fff0000u;
   }
 
@@ -2150,7 +2164,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
       const void* g = v ? (const void*)(dbase + dy_off[i]) : zero;
       glds16(g, ob + (i * 4 + wave) * 1024);
     }
-    const int hb = h0 * a.s - 1, wb = w0 * a.s - 1;
+    const int hb = ROW ? h0 + dh - 1 : h0 * a.s - 1, wb = w0 * a.s - 1;
     const char* sbase = (const char*)a.src + ((((long long)in_ * a.Hs + hb) * a.Ws + wb) * a.Ci) * 2;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
@@ -2165,9 +2179,9 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
     }
   };
 
-  f32x4 acc[9][MT][NT];
+  f32x4 acc[NTAP][MT][NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NTAP; ++t)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -2181,17 +2195,20 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
   for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      int p = kk * 32 + 8 * g + qq + 4 * h;
+      // ROW: a 32-lane half reads eight CONSECUTIVE pixels (the k index is summed over, any pixel <-> k-slot map
+      // that the two operands share is valid), which the 288-byte patch pitch spreads over all 64 banks
+      int p = ROW ? kk * 32 + 16 * (g >> 1) + 4 * (g & 1) + qq + 8 * h : kk * 32 + 8 * g + qq + 4 * h;
+      const int swz = ROW ? (p & (RBO / 32 - 1)) : tr_swz(p, RBO / 32);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
-        o_rd[kk][h][m] = p * RBO + (((wc * MT + m) ^ tr_swz(p, RBO / 32)) * 32) + pl * 8;
+        o_rd[kk][h][m] = p * RBO + (((wc * MT + m) ^ swz) * 32) + pl * 8;
       int r = p / a.TW, c = p - r * a.TW;
-      int pp = r < a.R ? (r * a.s + 1) * a.PC + c * a.s + 1 : a.PC + 1;
+      int pp = ROW ? (r < a.R ? r * a.PC + c + 1 : 1) : (r < a.R ? (r * a.s + 1) * a.PC + c * a.s + 1 : a.PC + 1);
       p_rd[kk][h] = 64 * RBO + pp * PBP + wi * NT * 32 + pl * 8;
     }
-  int toff[9];
+  int toff[NTAP];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) toff[t] = ((t / 3 - 1) * a.PC + (t % 3 - 1)) * PBP;
+  for (int t = 0; t < NTAP; ++t) toff[t] = ROW ? (t - 1) * PBP : ((t / 3 - 1) * a.PC + (t % 3 - 1)) * PBP;
 
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   const int nkt = kt1 - kt0;
@@ -2202,12 +2219,16 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
   // an s_waitcnt vmcnt(0) in front (it cannot tell the read from the LDS-DMA writes in flight), which would
   // serialise every K-step with the loads of the stages behind it.  With asm the waits are ours: the 18
   // (k-half, tap) groups of a K-step are software-pipelined DEPTH groups ahead with counted lgkmcnt.
-  constexpr int DEPTH = MT * NT >= 4 ? 2 : 3;
-  constexpr int NG = 18;
+  constexpr int DEPTH = ROW ? 1 : (MT * NT >= 4 ? 2 : 3);
+  constexpr int NG = 2 * NTAP;
   const unsigned smem_a = lds_addr(smem);
   for (int it = 0; it < nkt; ++it) {
     const int ahead = min(NST - 2, nkt - 1 - it);     // younger stages that may stay in flight
-    wait_vmcnt_dyn(ahead * LPS);
+    if (ROW) {                                        // 3-stage ring: one younger stage or none (no branch tree in the loop)
+      if (ahead > 0) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+    } else {
+      wait_vmcnt_dyn(ahead * LPS);
+    }
     __builtin_amdgcn_s_barrier();
     if (it + NST - 1 < nkt) { issue(ibuf); ibuf = ibuf + 1 == NST ? 0 : ibuf + 1; }
     const unsigned sb = smem_a + cbuf * a.stage;
@@ -2223,12 +2244,14 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
       }
     };
     auto readB = [&](int gi) {
-      const int kk = gi / 9, t = gi % 9, slot = gi % (DEPTH + 1);
+      const int kk = gi / NTAP, t = gi % NTAP, slot = gi % (DEPTH + 1);
       const unsigned alo = sb + p_rd[kk][0] + toff[t], ahi = sb + p_rd[kk][1] + toff[t];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        if (n == 0) { tr_read_asm<0>(xbr[slot][n][0], alo); tr_read_asm<0>(xbr[slot][n][1], ahi); }
-        else        { tr_read_asm<32>(xbr[slot][n][0], alo); tr_read_asm<32>(xbr[slot][n][1], ahi); }
+        if (n == 0)      { tr_read_asm<0>(xbr[slot][n][0], alo); tr_read_asm<0>(xbr[slot][n][1], ahi); }
+        else if (n == 1) { tr_read_asm<32>(xbr[slot][n][0], alo); tr_read_asm<32>(xbr[slot][n][1], ahi); }
+        else if (n == 2) { tr_read_asm<64>(xbr[slot][n][0], alo); tr_read_asm<64>(xbr[slot][n][1], ahi); }
+        else             { tr_read_asm<96>(xbr[slot][n][0], alo); tr_read_asm<96>(xbr[slot][n][1], ahi); }
       }
     };
     readA(0);
@@ -2236,14 +2259,14 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
     for (int gi = 0; gi < DEPTH; ++gi) readB(gi);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
-      const int kk = gi / 9, t = gi % 9, slot = gi % (DEPTH + 1);
+      const int kk = gi / NTAP, t = gi % NTAP, slot = gi % (DEPTH + 1);
       if (gi + DEPTH < NG) {
-        if (gi + DEPTH == 9) readA(1);
+        if (gi + DEPTH == NTAP) readA(1);
         readB(gi + DEPTH);
       }
       // LDS operations issued after group gi's reads: the younger B groups, and the kk = 1 dy fragments if
       // they went out after this group's reads (gi < 9) and have gone out already (gi + DEPTH >= 9)
-      const int younger = (NG - 1 - gi < DEPTH ? NG - 1 - gi : DEPTH) * 2 * NT + ((gi < 9 && gi + DEPTH >= 9) ? 2 * MT : 0);
+      const int younger = (NG - 1 - gi < DEPTH ? NG - 1 - gi : DEPTH) * 2 * NT + ((gi < NTAP && gi + DEPTH >= NTAP) ? 2 * MT : 0);
       wait_lgkm_dyn(younger);
 #pragma unroll
       for (int n = 0; n < NT; ++n) { touch(xbr[slot][n][0]); touch(xbr[slot][n][1]); }
@@ -2267,7 +2290,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
   if (a.dbg & 16) { if (acc[0][0][0][0] == 123.456f) a.dw[0] = 1.f; return; }
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NTAP; ++t)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -2275,8 +2298,14 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int co = co0 + (wc * MT + m) * 16 + fq * 4 + r;
-          int ci = (wi * NT + n) * 16 + fr;
-          if (co < a.Co && ci < a.Ci) atomicAdd(a.dw + ((long long)co * 9 + t) * a.Ci + ci, acc[t][m][n][r]);
+          int ci = ci0 + (wi * NT + n) * 16 + fr;
+          int tap = ROW ? dh * 3 + t : t;
+          if (co < a.Co && ci < a.Ci) {
+            float* q = a.dw + ((long long)co * 9 + tap) * a.Ci + ci;
+            // MGD_DBG=32: workgroup-scope atomics - measured identical in time (and result): no faster L2-side path
+            if (a.dbg & 32) __hip_atomic_fetch_add(q, acc[t][m][n][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else atomicAdd(q, acc[t][m][n][r]);
+          }
         }
 }
 
@@ -2912,6 +2941,30 @@ int launch_wgrad3(Wgrad3Args& a, hipStream_t st) {
   return 0;
 }
 
+// ROW form (one kernel row per block): grid = Co tiles x Ci slices x 3 kernel rows x pixel splits, one block per CU
+template <int MT, int NT, int PPW>
+int launch_wgrad3_row(Wgrad3Args& a, hipStream_t st) {
+  constexpr int BCO = 2 * MT * 16, BCI = 2 * NT * 16;
+  a.tilesCo = cdiv(a.Co, BCO);
+  a.tilesCi = a.Ci / BCI;
+  a.stage = 64 * BCO * 2 + 4 * PPW * 1024;
+  constexpr int OPW = (64 / (1024 / (BCO * 2))) / 4;
+  a.nst = 3;                                        // the kernel's counted wait assumes exactly three stages
+  size_t lds = (size_t)a.nst * a.stage;
+  const int cells = a.tilesCo * a.tilesCi * 3;
+  int splits = std::max(1, 256 / cells);             // one block per CU, ONE round: never more than 256 blocks
+  a.per_split = cdiv(a.ntiles, splits);
+  splits = cdiv(a.ntiles, a.per_split);
+  auto k = conv_wgrad3_kernel<MT, NT, PPW, true>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(cells * splits), dim3(256), lds, st, a);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
@@ -3110,6 +3163,33 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
     if (ci == 32) { if (w.s == 1) launch_wgrad3<2, 1, 3>(w, st); else launch_wgrad3<2, 1, 7>(w, st); }
     else          { if (w.s == 1) launch_wgrad3<2, 2, 5>(w, st); else launch_wgrad3<2, 2, 12>(w, st); }
     MGD_CHECK_LAUNCH("conv_wgrad3");
+    return MGD_OK;
+  }
+  // row form: 3x3 stride 1, Ci a multiple of 128, Co >= 128
+  static int rowform = -1;
+  if (rowform < 0) { const char* e = getenv("MGD_WGRAD_ROW"); rowform = e ? atoi(e) : 0; }   // opt-in: measured equal to v2
+  if (wvariant == 3 && rowform && std9 && ci % 128 == 0 && co >= 128 && d->in_stride == 1 && d->Hs == d->Hg &&
+      d->Ws == d->Wg && d->Wg >= 8) {
+    Wgrad3Args w;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MGD_DBG"); dbg = e ? atoi(e) : 0; } w.dbg = dbg; }
+    w.src = a.src; w.dy = a.dy; w.dw = a.dw;
+    w.N = d->N; w.Hs = d->Hs; w.Ws = d->Ws; w.Ci = ci; w.Hg = d->Hg; w.Wg = d->Wg; w.Co = co;
+    w.s = 1;
+    // output tile R x TW with R * TW <= 64 pixel slots: the shape that wastes the fewest slots on this map
+    int bestR = 4, bestTW = 16; double bestu = 0;
+    for (int tw = 8; tw <= 22; ++tw) {                 // patch = R x (TW + 2) pixels at 288 B must fit 24 pieces
+      int r = 64 / tw;
+      if (r < 1 || r * (tw + 2) * 288 > 24 * 1024) continue;
+      double u = (double)d->Hg * d->Wg / ((double)cdiv(d->Hg, r) * cdiv(d->Wg, tw) * 64.0);
+      if (u > bestu + 1e-9) { bestu = u; bestR = r; bestTW = tw; }
+    }
+    w.R = bestR; w.TW = bestTW;
+    w.PC = w.TW + 2;
+    w.PP = w.R * w.PC;
+    w.tilesH = cdiv(w.Hg, w.R); w.tilesW = cdiv(w.Wg, w.TW);
+    w.ntiles = w.N * w.tilesH * w.tilesW;
+    launch_wgrad3_row<4, 4, 6>(w, st);
+    MGD_CHECK_LAUNCH("conv_wgrad3_row");
     return MGD_OK;
   }
   if (co > 64 && ci > 64) launch_wgrad<2, 2, 4, 4>(a, st);

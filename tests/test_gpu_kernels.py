@@ -54,6 +54,8 @@ CONV_CASES = [
     (6, 100, 100, 128, 64, 1, 1),
     (2, 40, 36, 32, 64, 3, 1),           # patch-form weight gradient: Ci = 32, ragged tiles
     (2, 44, 40, 64, 128, 3, 2),          # patch-form weight gradient: Ci = 64, stride 2, ragged tiles
+    (2, 76, 76, 128, 256, 3, 1),         # kernel-row weight gradient (Ci >= 128): full tiles
+    (2, 21, 37, 256, 128, 3, 1),         # kernel-row weight gradient: non-square, ragged tiles, two Ci slices
 ]
 
 
@@ -155,6 +157,34 @@ def test_stem(dev):
     ops.stem_wgrad(img.to(dev), dy.to(dev), dw)
     torch.cuda.synchronize()
     np.testing.assert_allclose(dw.cpu().numpy() - 0.5, wr2.grad.numpy(), rtol=1e-3, atol=2e-3)
+
+
+def test_wgrad_kernel_row_form_opt_in():
+    """MGD_WGRAD_ROW=1 (read once per process, hence a child process): the kernel-row patch form of the weight
+    gradient for 3x3 stride-1 convs with Ci a multiple of 128 against torch autograd on the same bf16 inputs -
+    ragged tiles, ragged Co, two Ci slices."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import torch, torch.nn.functional as F
+        from multigriddet_amd import ops
+        torch.manual_seed(0)
+        for (N, H, W, Ci, Co) in ((2, 76, 76, 128, 256), (2, 21, 37, 256, 128), (1, 19, 19, 256, 704), (3, 38, 38, 128, 352)):
+            x = torch.randn(N, H, W, Ci).to(torch.bfloat16)
+            dy = torch.randn(N, H, W, Co).to(torch.bfloat16)
+            w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+            F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+            ref = w.grad.permute(0, 2, 3, 1).reshape(Co, 9, Ci)
+            dw = torch.full((Co, 9, Ci), 0.5, device="cuda")
+            ops.conv_wgrad(x.cuda(), dy.cuda(), dw, 3, 1)
+            torch.cuda.synchronize()
+            err = (dw.cpu() - 0.5 - ref).abs().max().item()
+            assert err <= 2e-3 * ref.abs().max().item() + 1e-3, (N, H, W, Ci, Co, err)
+        print("ROW_OK")
+    """)
+    env = dict(os.environ, MGD_WGRAD_ROW="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ROW_OK" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("N,H,W", [(2, 40, 48), (1, 37, 70), (3, 64, 130)])
