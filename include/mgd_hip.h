@@ -143,7 +143,7 @@ int mgd_pack_weights(const float* w, void* out, int Co, int T, int Ci, int trans
                      const int32_t* src_tap_host, int rows_pad, int K_pad, void* stream);
 
 /* All packed images of a network in ONE launch: `jobs_dev` is a device array of njobs descriptors sorted by
- * `begin` = index of the job's first 32x32 tile, a job having ntaps_out * ceil(cin/32) * ceil(rows/32) tiles
+ * `begin` = index of the job's first 32-row x 64-column tile, a job having ntaps_out * ceil(cin/64) * ceil(rows/32) tiles
  * (rows, cin = Co, Ci or swapped when transpose); total = number of tiles.  Only the valid region of each
  * image is written: the caller zero-fills the images once at allocation. */
 typedef struct mgd_pack_job {

@@ -2683,13 +2683,13 @@ struct PackJob {
   long long begin;   // first flat element index of this job
 };
 
-// One block = one 32 x 32 tile of one packed image (output rows r0.., columns t*cin + c0..); the tile is read
-// along the source's contiguous index (ci for forward images, the OUTPUT-row index for transposed/data-gradient
-// images) and transposed through LDS when needed, so both sides are coalesced.  Only the valid region is
-// written: the zero padding of the images is written once at allocation and never changes.
-// `begin` of a job here = index of its first tile.
+// One block iteration = one 32-row x 64-column tile of one packed image (output rows r0.., columns t*cin + c0..); the
+// tile is read along the source's contiguous index (ci for forward images, the OUTPUT-row index for transposed /
+// data-gradient images) and transposed through LDS when needed, so both sides are coalesced: 128-byte source rows,
+// 128-byte bf16 output rows (two columns per thread).  Only the valid region is written: the zero padding of the
+// images is written once at allocation and never changes.  `begin` of a job = index of its first tile.
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs, long long total) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[64][33];
   for (long long bt = blockIdx.x; bt < total; bt += gridDim.x) {
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {
@@ -2698,33 +2698,51 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restri
     }
     const PackJob J = jobs[lo];
     const int rows = J.transpose ? J.Ci : J.Co, cin = J.transpose ? J.Co : J.Ci;
-    const int tr = (rows + 31) >> 5, tcn = (cin + 31) >> 5;
+    const int tr = (rows + 31) >> 5, tcn = (cin + 63) >> 6;
     int e = (int)(bt - J.begin);
     const int rt = e % tr; e /= tr;
     const int ct = e % tcn;
     const int t = e / tcn;
     const int st = (int)((J.srccode >> (4 * t)) & 15);
-    const int r0 = rt * 32, c0 = ct * 32;
+    const int r0 = rt * 32, c0 = ct * 64;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const bool even = !((J.Ci | J.Co) & 1) && !(((uintptr_t)J.w) & 7);   // paired 4-byte stores / 8-byte loads are aligned
     if (J.transpose) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 8; ++j) {
         int c = c0 + ty + 8 * j, r = r0 + tx;
         tile[ty + 8 * j][tx] = (c < cin && r < rows) ? J.w[((long long)c * J.T + st) * J.Ci + r] : 0.f;
       }
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int r = r0 + ty + 8 * j, c = c0 + tx;
-        if (r < rows && c < cin) J.out[(long long)r * J.K_pad + t * cin + c] = f2bf(tile[tx][ty + 8 * j]);
+        int r = r0 + ty + 8 * j, c = c0 + 2 * tx;
+        if (r < rows && c < cin) {
+          bf16_t* o = J.out + (long long)r * J.K_pad + t * cin + c;
+          if (even) {
+            *(uint32_t*)o = pack2bf(tile[2 * tx][ty + 8 * j], tile[2 * tx + 1][ty + 8 * j]);
+          } else {                                    // odd channel counts: element-wise, nothing outside the tap's columns
+            o[0] = f2bf(tile[2 * tx][ty + 8 * j]);
+            if (c + 1 < cin) o[1] = f2bf(tile[2 * tx + 1][ty + 8 * j]);
+          }
+        }
       }
       __syncthreads();
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int r = r0 + ty + 8 * j, c = c0 + tx;
-        if (r < rows && c < cin)
-          J.out[(long long)r * J.K_pad + t * cin + c] = f2bf(J.w[((long long)r * J.T + st) * J.Ci + c]);
+        int r = r0 + ty + 8 * j, c = c0 + 2 * tx;
+        if (r < rows && c < cin) {
+          const float* wsrc = J.w + ((long long)r * J.T + st) * J.Ci + c;
+          bf16_t* o = J.out + (long long)r * J.K_pad + t * cin + c;
+          if (even) {
+            float2 v = *(const float2*)wsrc;
+            *(uint32_t*)o = pack2bf(v.x, v.y);
+          } else {
+            o[0] = f2bf(wsrc[0]);
+            if (c + 1 < cin) o[1] = f2bf(wsrc[1]);
+          }
+        }
       }
     }
   }
@@ -3270,7 +3288,7 @@ extern "C" int mgd_stem_im2col(const float* image, void* out, int N, int H, int 
 extern "C" int mgd_pack_weights_batch(const mgd_pack_job* jobs_dev, int njobs, int64_t total, void* stream) {
   MGD_REQUIRE(jobs_dev && njobs >= 1 && total >= 1, "pack_batch: bad arguments");
   static_assert(sizeof(mgd_pack_job) == sizeof(PackJob), "mgd_pack_job layout");
-  long long g = total;               // total = number of 32x32 tiles over all jobs
+  long long g = total;               // total = number of 32x64 tiles over all jobs
   if (g > 256 * 64) g = 256 * 64;
   hipLaunchKernelGGL(pack_batch_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs_dev, njobs,
                      (long long)total);

@@ -128,7 +128,7 @@ class PackBatch:
                     code |= int(sidx) << (4 * t)
                 j.srccode, j.begin = code, begin
                 rows, cin = (pk.ci_master, pk.co) if tr else (pk.co, pk.ci_master)
-                begin += nt * (-(-cin // 32)) * (-(-rows // 32))      # 32x32 tiles of the valid region
+                begin += nt * (-(-cin // 64)) * (-(-rows // 32))      # 32-row x 64-column tiles of the valid region
                 jobs.append(j)
         self.n, self.total = len(jobs), begin
         arr = (L.PackJob * len(jobs))(*jobs)
