@@ -332,6 +332,18 @@ int mgd_gridmask(float* images, float* boxes, int B, int S, int M, const int32_t
 int mgd_mixup(const float* images, const float* boxes, int B, int S, int M_in, const int32_t* partner /*[B]*/,
               const float* lam /*[B]*/, float* out_images, float* out_boxes, int M_out, void* stream);
 
+/* ---- data-parallel exchange (the reference has no multi-GPU path, trainers/trainer.py:430-594 runs one
+ * device).  One process per GPU; the only collective of the path is the SUM of the flat fp32 gradient buffer, cut into
+ * buckets that are launched while backward is still running.  Thin RCCL binding (librccl is opened lazily): rank 0
+ * draws a 128-byte id with mgd_comm_unique_id and hands it to the other ranks out of band (torch.distributed store,
+ * MPI, a file); every rank then calls mgd_comm_init on its own current device.  mgd_comm_allreduce_bucket is in
+ * place, asynchronous on `stream`, and must be called in the same bucket order on every rank. */
+#define MGD_COMM_ID_BYTES 128
+int mgd_comm_unique_id(void* id128);
+int mgd_comm_init(void** comm, int rank, int world, const void* id128);
+int mgd_comm_allreduce_bucket(void* comm, float* grads, int64_t count, void* stream);
+int mgd_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

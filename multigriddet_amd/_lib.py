@@ -105,6 +105,7 @@ EXPORTS = [
     "mgd_adam_step", "mgd_adam_step_dev", "mgd_sgd_step", "mgd_build_targets_workspace_size", "mgd_build_targets",
     "mgd_loss_workspace_size", "mgd_loss_fwd_bwd", "mgd_decode_workspace_size", "mgd_decode",
     "mgd_nms_workspace_size", "mgd_nms", "mgd_wbf_workspace_size", "mgd_wbf", "mgd_iou_matrix", "mgd_eval_match", "mgd_mosaic", "mgd_gridmask", "mgd_mixup",
+    "mgd_comm_unique_id", "mgd_comm_init", "mgd_comm_allreduce_bucket", "mgd_comm_destroy",
 ]
 
 

@@ -25,8 +25,51 @@ def make_buckets(layer_offsets, n_params, bucket_elems):
     return buckets
 
 
+class CabiComm:
+    """The library's own RCCL binding (include/mgd_hip.h `mgd_comm_*`): one communicator per process on the current
+    device.  The 128-byte id is drawn by rank 0 and travels through the already initialised torch.distributed group
+    (any backend - it is host bytes)."""
+
+    def __init__(self, rank, world, device):
+        import ctypes as C
+        from . import _lib as L
+        self._L, self._C = L, C
+        lib = L.load()
+        idbuf = (C.c_ubyte * 128)()
+        if rank == 0:
+            L.check(lib.mgd_comm_unique_id(idbuf), "comm_unique_id")
+        if world > 1:
+            box = [bytes(idbuf)]
+            dist.broadcast_object_list(box, src=0)
+            idbuf = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        self.comm = C.c_void_p()
+        with torch.cuda.device(device):
+            L.check(lib.mgd_comm_init(C.byref(self.comm), int(rank), int(world), idbuf), "comm_init")
+
+    def all_reduce_sum_(self, flat_fp32):
+        """In place, asynchronous on the current stream."""
+        L, C = self._L, self._C
+        assert flat_fp32.dtype == torch.float32 and flat_fp32.is_cuda and flat_fp32.is_contiguous()
+        L.check(L.load().mgd_comm_allreduce_bucket(self.comm, L.ptr(flat_fp32), C.c_int64(flat_fp32.numel()),
+                                                   L.stream_ptr()), "comm_allreduce_bucket")
+
+    def destroy(self):
+        if self.comm:
+            self._L.check(self._L.load().mgd_comm_destroy(self.comm), "comm_destroy")
+            self.comm = self._C.c_void_p()
+
+
+class _Done:
+    def wait(self):
+        pass
+
+
 class GradBuckets:
-    def __init__(self, grads, layer_offsets, world_size, bucket_mb=32.0, comm_stream=None, producer_streams=()):
+    def __init__(self, grads, layer_offsets, world_size, bucket_mb=32.0, comm_stream=None, producer_streams=(),
+                 cabi_comm=None):
+        """cabi_comm: a CabiComm - buckets then go through mgd_comm_allreduce_bucket on the communication stream
+        instead of torch.distributed (opt-in, MGD_DP_COMM=cabi in TrainStep; same bucket order, same overlap)."""
+        self.cabi = cabi_comm
         self.grads = grads
         self.producer_streams = tuple(producer_streams)     # side streams that also write gradients (wgrad)
         self.world = world_size
@@ -57,7 +100,11 @@ class GradBuckets:
                 for ps in self.producer_streams:
                     self.comm_stream.wait_stream(ps)
                 with torch.cuda.stream(self.comm_stream):
-                    self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
+                    if self.cabi is not None:
+                        self.cabi.all_reduce_sum_(sl)
+                        self._works.append(_Done())
+                    else:
+                        self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
             else:
                 self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
 
@@ -65,4 +112,6 @@ class GradBuckets:
         self.on_layer_done(0)
         for w in self._works:
             w.wait()
+        if self.cabi is not None and self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)     # the optimiser reads the summed gradients
         self._works = []

@@ -6,6 +6,8 @@ the train model of models/multigriddet_darknet.py:551-751 and the tf.data target
 data/generators.py:2112).  The reference is single-device; data parallelism here is new design:
 one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI), gradients averaged.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -36,8 +38,13 @@ class TrainStep:
         self._loss = {}
         self._douts = {}
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
+        cabi = None
+        if world_size > 1 and os.environ.get("MGD_DP_COMM", "torch") == "cabi":
+            import torch.distributed as dist
+            from .dp import CabiComm
+            cabi = CabiComm(dist.get_rank(), world_size, dev)       # the library's own RCCL binding (mgd_comm_*)
         self.dp = GradBuckets(net.grads, [cv.off_w for cv in net.layers], world_size, bucket_mb, self.comm_stream,
-                              producer_streams=(net.wg_stream,))
+                              producer_streams=(net.wg_stream,), cabi_comm=cabi)
         self.main_stream = torch.cuda.Stream(device=dev, priority=-1)
         # hipGraph replay of the whole step (single process, Adam/AdamW): see enable_graph()
         self.use_graph = False

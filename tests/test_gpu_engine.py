@@ -329,3 +329,28 @@ def test_inference_graph_replay_matches_eager(fold):
     torch.cuda.synchronize()
     for o, e in zip(o2, e2):
         assert torch.equal(o, e)
+
+
+def test_cabi_rccl_communicator_single_rank():
+    """mgd_comm_* (the library's RCCL binding for the gradient sum): a one-rank communicator on this GPU - the sum over
+    one rank is the identity, in place, stream-ordered; error paths return MGD_EINVAL with a message."""
+    import ctypes as C
+    import torch
+    from multigriddet_amd import _lib as L
+    from multigriddet_amd.dp import CabiComm
+    comm = CabiComm(0, 1, torch.device("cuda:0"))
+    g = torch.randn(3_000_001, device="cuda")
+    ref = g.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        comm.all_reduce_sum_(g[:2_000_000])
+        comm.all_reduce_sum_(g[2_000_000:])
+    side.synchronize()
+    assert torch.equal(g, ref)
+    lib = L.load()
+    assert lib.mgd_comm_allreduce_bucket(None, L.ptr(g), C.c_int64(4), None) == -1
+    assert b"comm_allreduce_bucket" in lib.mgd_last_error()
+    assert lib.mgd_comm_init(None, 0, 1, None) == -1
+    comm.destroy()
+    comm.destroy()          # idempotent
