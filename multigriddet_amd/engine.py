@@ -124,6 +124,7 @@ class Network:
         # leave idle.  Needs one dy buffer per layer (no scratch reuse while a side-stream wgrad may read it).
         self.overlap_wgrad = True
         self.wg_stream = torch.cuda.Stream(device=dev)
+        self.side_bias_grad = True      # bias gradients of the prediction convs ride on the weight-gradient side stream
         self.fuse_stem_bn = True        # stem: BN backward applied inside the weight-gradient kernel (dy0 never written)
         self.fuse_bn_reduce = True      # BN-backward reduction inside the dgrad epilogue that produces `da` (A/B: 0.9 ms/step faster)
         self._arenas = {}
@@ -366,15 +367,21 @@ class Network:
                        reduced=i in A["reduced"])
         return dy
 
-    def _wgrad(self, x, dy, dw, k, s):
+    def _wgrad(self, x, dy, dw, k, s, dbias=None):
+        """Weight gradient (and, for the biased prediction convs, the bias gradient: nothing on the dgrad/BN chain
+        reads it, so it leaves the critical stream too)."""
         if not self.overlap_wgrad:
             ops.conv_wgrad(x, dy, dw, k, s)
+            if dbias is not None:
+                ops.bias_grad(dy, dbias)
             return
         ev = torch.cuda.Event()
         ev.record()
         self.wg_stream.wait_event(ev)
         with torch.cuda.stream(self.wg_stream):
             ops.conv_wgrad(x, dy, dw, k, s)
+            if dbias is not None:
+                ops.bias_grad(dy, dbias)
 
     def backward(self, douts, on_layer_done=None):
         """douts: three bf16 grads wrt the head outputs.  Accumulates into self.grads (zero it first).
@@ -405,8 +412,11 @@ class Network:
             pred = Lr[c5]
             dy5 = douts[sc]
             a4 = acts[c4]
-            ops.bias_grad(dy5, pred.dbias)
-            self._wgrad(a4, dy5, pred.dw, 1, 1)
+            if self.side_bias_grad:
+                self._wgrad(a4, dy5, pred.dw, 1, 1, dbias=pred.dbias)
+            else:
+                ops.bias_grad(dy5, pred.dbias)
+                self._wgrad(a4, dy5, pred.dw, 1, 1)
             if on_layer_done and pred_only:
                 on_layer_done(c5)
             if pred_only:
