@@ -48,6 +48,7 @@ class TrainStep:
         self.main_stream = torch.cuda.Stream(device=dev, priority=-1)
         # hipGraph replay of the whole step (single process, Adam/AdamW): see enable_graph()
         self.use_graph = False
+        self.early_optimizer = True     # see _step_body
         self._graphs = {}
         self._hyper = torch.zeros(2, dtype=torch.float32, device=dev)
 
@@ -145,10 +146,52 @@ class TrainStep:
             self.dp.reset(lo=rng_[0] if rng_ else 0)
             net.backward(douts, on_layer_done=self.dp.on_layer_done)
             self.dp.finish()      # makes the compute stream wait for the collectives
+            self.apply_optimizer(dev_hyper=dev_hyper)
+        elif self._early_ok():
+            # Adam + re-pack of the layers whose gradients are final early (stage 5 + head: two thirds of the parameters)
+            # go to the weight-gradient side stream in the middle of backward - HBM-bound work under the MFMA-bound
+            # data-gradient chain - instead of sitting on the serial tail of the step
+            from .engine import EARLY_SPLIT
+            split_off = net.layers[EARLY_SPLIT].off_w
+
+            def hook(ld):
+                if ld != EARLY_SPLIT:
+                    return
+                ev = torch.cuda.Event()
+                ev.record()
+                net.wg_stream.wait_event(ev)          # BN-affine gradients of these layers come from the main stream
+                with torch.cuda.stream(net.wg_stream):
+                    self._optimizer_range(split_off, net.n_params, dev_hyper)
+                    net._pack_hi.run()
+            net.backward(douts, on_layer_done=hook)   # ends with the main stream joined to the side stream
+            self._optimizer_range(0, split_off, dev_hyper)
+            net._pack_lo.run()
         else:
             net.backward(douts)
-        self.apply_optimizer(dev_hyper=dev_hyper)
+            self.apply_optimizer(dev_hyper=dev_hyper)
         return comp
+
+    def _early_ok(self):
+        net = self.net
+        return (self.early_optimizer and self.world == 1 and net.overlap_wgrad and not net.freeze_backbone
+                and not net.freeze_all_but_pred)
+
+    def _optimizer_range(self, b, e, dev_hyper=False):
+        """One optimiser launch over the flat slice [b, e) on the current stream."""
+        net = self.net
+        gs = 1.0 / self.world
+        p, g, m = net.params[b:e], net.grads[b:e], self.m[b:e]
+        if self.optimizer in ("adam", "adamw"):
+            b1, b2 = self.opt_kwargs.get("beta_1", 0.9), self.opt_kwargs.get("beta_2", 0.999)
+            eps = self.opt_kwargs.get("epsilon", 1e-7)
+            if dev_hyper:
+                ops.adam_step_dev(p, g, m, self.v[b:e], self._hyper, b1=b1, b2=b2, eps=eps, grad_scale=gs)
+            else:
+                ops.adam_step(p, g, m, self.v[b:e], self.lr, self.step_count, b1=b1, b2=b2, eps=eps, grad_scale=gs,
+                              weight_decay=self.opt_kwargs.get("weight_decay", 5e-4) if self.optimizer == "adamw" else 0.0)
+        else:
+            ops.sgd_step(p, g, m, self.lr, momentum=self.opt_kwargs.get("momentum", 0.937),
+                         nesterov=self.opt_kwargs.get("nesterov", True), grad_scale=gs)
 
     def apply_optimizer(self, dev_hyper=False):
         """step_count has been advanced by the caller."""
@@ -159,18 +202,7 @@ class TrainStep:
         else:
             ranges = [net.trainable_range()]
         for b, e in ranges:
-            p, g, m = net.params[b:e], net.grads[b:e], self.m[b:e]
-            if self.optimizer in ("adam", "adamw"):
-                b1, b2 = self.opt_kwargs.get("beta_1", 0.9), self.opt_kwargs.get("beta_2", 0.999)
-                eps = self.opt_kwargs.get("epsilon", 1e-7)
-                if dev_hyper:
-                    ops.adam_step_dev(p, g, m, self.v[b:e], self._hyper, b1=b1, b2=b2, eps=eps, grad_scale=gs)
-                else:
-                    ops.adam_step(p, g, m, self.v[b:e], self.lr, self.step_count, b1=b1, b2=b2, eps=eps, grad_scale=gs,
-                                  weight_decay=self.opt_kwargs.get("weight_decay", 5e-4) if self.optimizer == "adamw" else 0.0)
-            else:
-                ops.sgd_step(p, g, m, self.lr, momentum=self.opt_kwargs.get("momentum", 0.937),
-                             nesterov=self.opt_kwargs.get("nesterov", True), grad_scale=gs)
+            self._optimizer_range(b, e, dev_hyper)
         first = 0
         if net.freeze_backbone:
             first = 52

@@ -354,3 +354,49 @@ def test_cabi_rccl_communicator_single_rank():
     assert lib.mgd_comm_init(None, 0, 1, None) == -1
     comm.destroy()
     comm.destroy()          # idempotent
+
+
+def test_early_optimizer_matches_tail_optimizer():
+    """TrainStep.early_optimizer: Adam + re-pack of stage 5 and the head on the side stream in the middle of backward
+    against the single optimiser launch at the end of the step.  After ONE step from identical weights the two differ
+    only by the last-bit noise of the weight-gradient atomics (first moments equal to 1e-3 relative; Adam's first step
+    is lr * sign(g), so isolated near-zero gradients may flip by 2 lr); further steps are compared on the loss only.
+    The packed images always equal a fresh pack of the final masters."""
+    import torch
+    from multigriddet_amd.engine import Network
+    from multigriddet_amd.train_step import TrainStep
+    import bench
+    dev = torch.device("cuda:0")
+    img, bx = bench.synth_batch(0, 4, 256)
+    img, bx = torch.from_numpy(img).to(dev), torch.from_numpy(bx).to(dev)
+    res = {}
+    lr = 1e-4
+    for mode in (False, True):
+        net = Network(80, 3, dev, seed=0)
+        ts = TrainStep(net, bench.coco_anchors(), 80, (256, 256), 4, lr=lr)
+        ts.early_optimizer = mode
+        assert ts._early_ok() == mode
+        # fixed (moving) BatchNorm statistics: the net is then a fixed piecewise-linear map and two runs differ by the
+        # atomics' last bits only - with batch statistics the same comparison drowns in chaotic amplification (after one
+        # step two runs of the SAME mode already differ by 0.4 lr on average); the stream choreography is identical
+        net.freeze_bn = True
+        losses = [float(ts.step(img, bx)[7])]
+        torch.cuda.synchronize()
+        p1, m1 = net.params.clone(), ts.m.clone()
+        losses += [float(ts.step(img, bx)[7]) for _ in range(3)]
+        torch.cuda.synchronize()
+        with_pk = [cv for cv in net.layers if cv.pk is not None]
+        packed = [cv.pk.fwd.clone() for cv in with_pk]
+        net.refresh_packed()
+        torch.cuda.synchronize()
+        for a, cv in zip(packed, with_pk):
+            assert torch.equal(a.view(torch.int16), cv.pk.fwd.view(torch.int16))
+        res[mode] = (np.array(losses), p1, m1)
+    la, pa, ma = res[False]
+    lb, pb, mb = res[True]
+    np.testing.assert_allclose(lb, la, rtol=2e-2)
+    assert abs(la[0] - lb[0]) <= 2e-3 * abs(la[0])  # same weights; BatchNorm statistics are summed with float atomics
+    d = (pa - pb).abs()
+    assert d.max().item() <= 2.5 * lr
+    assert d.mean().item() <= 0.02 * lr
+    assert (ma - mb).abs().max().item() <= 1e-3 * ma.abs().max().item() + 1e-7
