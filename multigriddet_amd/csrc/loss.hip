@@ -55,8 +55,10 @@ __device__ __forceinline__ float norm_factor(const mgd_loss_cfg& c, int l, int n
 }
 
 // ---- K1: collect the per-image GT list (every positive cell) and the counters
-__global__ void loss_prep_kernel(LossArgs a, int l) {
+// One launch for all scales: blockIdx.y = scale (blocks past a small scale's cells leave at once).
+__global__ void loss_prep_kernel(LossArgs a) {
   const mgd_loss_cfg& c = a.cfg;
+  const int l = blockIdx.y;
   const int gh = c.grid_h[l], gw = c.grid_w[l], F = 5 + c.A + c.C;
   long long ncell = (long long)c.B * gh * gw;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,9 +84,15 @@ __global__ void loss_prep_kernel(LossArgs a, int l) {
 }
 
 // ---- K2: per-cell loss and gradient.  grid = (cells chunks, B, 1) per scale.
-__global__ __launch_bounds__(256) void loss_cell_kernel(LossArgs a, int l, int cpb) {
+struct CellsPerBlock { int v[MAXL]; };
+
+// One launch for all scales: blockIdx.z = scale, blockIdx.y = image, blockIdx.x = chunk of cpb.v[scale] cells; the
+// three scales are independent and the small ones are latency bound, so they run under the large one.
+__global__ __launch_bounds__(256) void loss_cell_kernel(LossArgs a, CellsPerBlock cpbs) {
   const mgd_loss_cfg& c = a.cfg;
+  const int l = blockIdx.z, cpb = cpbs.v[l];
   const int gh = c.grid_h[l], gw = c.grid_w[l], A = c.A, C = c.C, F = 5 + A + C;
+  if ((int)blockIdx.x * cpb >= gh * gw) return;      // block-uniform: this scale has fewer chunks than the widest one
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float4 gts[GT_LDS];
@@ -426,12 +434,14 @@ extern "C" int mgd_loss_fwd_bwd(const mgd_loss_cfg* cfg, const float* const* y_p
   }
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(base, 0, w.gt, st) != hipSuccess) return mgd_set_error(MGD_ELAUNCH, "loss: memset failed");
+  long long max_cell = 0;
+  for (int l = 0; l < cfg->L; ++l) max_cell = std::max(max_cell, (long long)cfg->B * cfg->grid_h[l] * cfg->grid_w[l]);
+  hipLaunchKernelGGL(loss_prep_kernel, dim3(cdiv(max_cell, 256), cfg->L), dim3(256), 0, st, a);
+  LossArgs al = a;
+  CellsPerBlock cpbs;
+  int max_gx = 1;
+  for (int l = 0; l < MAXL; ++l) cpbs.v[l] = CELLS_PER_BLOCK;
   for (int l = 0; l < cfg->L; ++l) {
-    long long ncell = (long long)cfg->B * cfg->grid_h[l] * cfg->grid_w[l];
-    hipLaunchKernelGGL(loss_prep_kernel, dim3(cdiv(ncell, 256)), dim3(256), 0, st, a, l);
-  }
-  for (int l = 0; l < cfg->L; ++l) {
-    LossArgs al = a;
     if (scratch_used[l]) al.gb[l] = nullptr;    // bf16 image is produced after the consensus scatter
     // a wave walks its cells one after the other and every cell is a dependent chain of global loads, so the launch
     // is latency bound: 64 cells per block left the 19x19 grid on 96 blocks (69 us for 5776 cells).  Aim for >= 2048
@@ -439,9 +449,10 @@ extern "C" int mgd_loss_fwd_bwd(const mgd_loss_cfg* cfg, const float* const* y_p
     const int cells = cfg->grid_h[l] * cfg->grid_w[l];
     int cpb = CELLS_PER_BLOCK;
     while (cpb > 4 && (long long)cdiv(cells, cpb) * cfg->B < 2048) cpb >>= 1;
-    int gx = cdiv(cells, cpb);
-    hipLaunchKernelGGL(loss_cell_kernel, dim3(gx, cfg->B), dim3(256), 0, st, al, l, cpb);
+    cpbs.v[l] = cpb;
+    max_gx = std::max(max_gx, (int)cdiv(cells, cpb));
   }
+  hipLaunchKernelGGL(loss_cell_kernel, dim3(max_gx, cfg->B, cfg->L), dim3(256), 0, st, al, cpbs);
   if (cfg->use_consensus_loss) {
     for (int l = 0; l < cfg->L; ++l) {
       if (!a.gf[l]) continue;
