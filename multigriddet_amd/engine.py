@@ -18,7 +18,7 @@ from . import ops
 
 STAGES = ((64, 1), (128, 2), (256, 8), (512, 8), (1024, 4))
 BACKBONE_CONVS = 52
-EARLY_SPLIT = 43          # first conv of backbone stage 5 (512 -> 1024, stride 2)
+EARLY_SPLITS = (43, 26)   # first convs of backbone stages 5 and 4 (the stride-2 convs): 67 % + 26 % of the parameters
 
 
 def conv_specs(num_classes=80, num_anchors=3):
@@ -116,10 +116,14 @@ class Network:
                 cv.wpack = cv.w
         self._pack_all = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers if cv.pk is not None], dev)
         self._pack_head = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers[BACKBONE_CONVS:]], dev)
-        # early-optimiser split: layers >= EARLY_SPLIT (stage 5 of the backbone + the head, two thirds of the parameters)
-        # have their gradients long before backward ends
-        self._pack_hi = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers[EARLY_SPLIT:]], dev)
-        self._pack_lo = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers[:EARLY_SPLIT] if cv.pk is not None], dev)
+        # early-optimiser segments: stage 5 of the backbone + the head, then stage 4, have their gradients long before
+        # backward ends
+        # segments [EARLY_SPLITS[k], EARLY_SPLITS[k-1]) from the end of the network, then the rest
+        self._pack_seg = []
+        hi = len(self.layers)
+        for lo in EARLY_SPLITS + (0,):
+            self._pack_seg.append(ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers[lo:hi] if cv.pk is not None], dev))
+            hi = lo
         self.training = True
         self.freeze_backbone = False
         self.freeze_all_but_pred = False

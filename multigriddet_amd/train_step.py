@@ -148,24 +148,26 @@ class TrainStep:
             self.dp.finish()      # makes the compute stream wait for the collectives
             self.apply_optimizer(dev_hyper=dev_hyper)
         elif self._early_ok():
-            # Adam + re-pack of the layers whose gradients are final early (stage 5 + head: two thirds of the parameters)
-            # go to the weight-gradient side stream in the middle of backward - HBM-bound work under the MFMA-bound
-            # data-gradient chain - instead of sitting on the serial tail of the step
-            from .engine import EARLY_SPLIT
-            split_off = net.layers[EARLY_SPLIT].off_w
+            # Adam + re-pack of the layers whose gradients are final early (stage 5 + head: two thirds of the parameters,
+            # then stage 4: another quarter) go to the weight-gradient side stream in the middle of backward - HBM-bound
+            # work under the MFMA-bound data-gradient chain - instead of sitting on the serial tail of the step
+            from .engine import EARLY_SPLITS
+            offs = [net.layers[l].off_w for l in EARLY_SPLITS]
+            ends = [net.n_params] + offs[:-1]
 
             def hook(ld):
-                if ld != EARLY_SPLIT:
+                if ld not in EARLY_SPLITS:
                     return
+                k = EARLY_SPLITS.index(ld)
                 ev = torch.cuda.Event()
                 ev.record()
                 net.wg_stream.wait_event(ev)          # BN-affine gradients of these layers come from the main stream
                 with torch.cuda.stream(net.wg_stream):
-                    self._optimizer_range(split_off, net.n_params, dev_hyper)
-                    net._pack_hi.run()
+                    self._optimizer_range(offs[k], ends[k], dev_hyper)
+                    net._pack_seg[k].run()
             net.backward(douts, on_layer_done=hook)   # ends with the main stream joined to the side stream
-            self._optimizer_range(0, split_off, dev_hyper)
-            net._pack_lo.run()
+            self._optimizer_range(0, offs[-1], dev_hyper)
+            net._pack_seg[-1].run()
         else:
             net.backward(douts)
             self.apply_optimizer(dev_hyper=dev_hyper)
