@@ -105,6 +105,29 @@ __global__ __launch_bounds__(256) void bn_act_fwd_fused_kernel(const float* __re
   const int CV = C >> 3;
   const int CVB = CV < 32 ? CV : 32;
   const int PL = 256 / CVB;
+  const int oct = blockIdx.y * 32 + (threadIdx.x % CVB);
+  const int pl = threadIdx.x / CVB;
+  const bool active = oct < CV && pl < PL;
+  // The first tile of activations is requested BEFORE the statistics are folded: the parameter phase is a chain of
+  // dependent round trips (replicas -> barrier -> parameters) that the data loads do not depend on, and a small layer
+  // is one tile per thread - so its launch costs one memory round trip instead of three (it matters most inside the
+  // backward pass, where the weight-gradient stream multiplies the latency of every round trip).
+  constexpr int U = 4;
+  const long long stride = (long long)gridDim.x * PL;
+  const long long pstart = (long long)blockIdx.x * PL + pl;
+  uint4 yv[U], rv[U];
+  auto fetch = [&](long long p0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long long p = p0 + u * stride;
+      if (p < P) {
+        long long e = p * C + oct * 8;
+        yv[u] = *(const uint4*)(y + e);
+        if (res) rv[u] = *(const uint4*)(res + e);
+      }
+    }
+  };
+  if (active && pstart < P) fetch(pstart);
   {
     int c = blockIdx.y * 256 + threadIdx.x;
     float sc = 0.f, sh = 0.f;
@@ -136,28 +159,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_fused_kernel(const float* __re
     prm[1][threadIdx.x] = sh;
   }
   __syncthreads();
-  const int oct = blockIdx.y * 32 + (threadIdx.x % CVB);
-  const int pl = threadIdx.x / CVB;
-  if (!(oct < CV && pl < PL)) return;
+  if (!active) return;
   float sc[8], sh[8];
   {
     int lo = (threadIdx.x % CVB) * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = prm[0][lo + j]; sh[j] = prm[1][lo + j]; }
   }
-  constexpr int U = 4;
-  const long long stride = (long long)gridDim.x * PL;
-  for (long long p0 = (long long)blockIdx.x * PL + pl; p0 < P; p0 += stride * U) {
-    uint4 yv[U], rv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      long long p = p0 + u * stride;
-      if (p < P) {
-        long long e = p * C + oct * 8;
-        yv[u] = *(const uint4*)(y + e);
-        if (res) rv[u] = *(const uint4*)(res + e);
-      }
-    }
+  for (long long p0 = pstart; p0 < P; p0 += stride * U) {
+    if (p0 != pstart) fetch(p0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       long long p = p0 + u * stride;
@@ -208,6 +218,30 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
   const int oct = blockIdx.y * 32 + (threadIdx.x % CVB);
   const int pl = threadIdx.x / CVB;
   const bool active = oct < CV && pl < PL;
+  // first tile and per-channel parameters requested before the replica fold (see bn_act_fwd_fused_kernel)
+  constexpr int U = 4;                        // pixels in flight per thread: 8 x 16-byte loads before any use
+  const long long stride = (long long)gridDim.x * PL;
+  const long long pstart = (long long)blockIdx.x * PL + pl;
+  uint4 gv[U], yv[U];
+  auto fetch = [&](long long p0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long long p = p0 + u * stride;
+      if (p < P) {
+        long long e = p * C + oct * 8;
+        gv[u] = *(const uint4*)(da + e);
+        yv[u] = *(const uint4*)(y + e);
+      }
+    }
+  };
+  float sc[8], sh[8], mu[8], iv[8], m1[8], m2[8];
+  if (active) {
+    if (pstart < P) fetch(pstart);
+    load8(scale + oct * 8, sc);
+    load8(shift + oct * 8, sh);
+    load8(smean + oct * 8, mu);
+    load8(sinv + oct * 8, iv);
+  }
   if (APPLY && !frozen) {
     // fold the R replicas for this block's channel window: thread t <-> channel blockIdx.y*256 + t
     int c = blockIdx.y * 256 + threadIdx.x;
@@ -224,35 +258,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
     red[1][threadIdx.x] = sb * invP;
     __syncthreads();
   }
-  float sc[8], sh[8], mu[8], iv[8], m1[8], m2[8];
-  if (active) {
-    load8(scale + oct * 8, sc);
-    load8(shift + oct * 8, sh);
-    load8(smean + oct * 8, mu);
-    load8(sinv + oct * 8, iv);
-    if (APPLY && !frozen) {
-      int lo = (threadIdx.x % CVB) * 8;
+  if (active && APPLY && !frozen) {
+    int lo = (threadIdx.x % CVB) * 8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { m1[j] = red[0][lo + j]; m2[j] = red[1][lo + j]; }
-    }
+    for (int j = 0; j < 8; ++j) { m1[j] = red[0][lo + j]; m2[j] = red[1][lo + j]; }
   }
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
   if (active) {
-    constexpr int U = 4;                      // pixels in flight per thread: 8 x 16-byte loads before any use
-    const long long stride = (long long)gridDim.x * PL;
-    for (long long p0 = (long long)blockIdx.x * PL + pl; p0 < P; p0 += stride * U) {
-      uint4 gv[U], yv[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        long long p = p0 + u * stride;
-        if (p < P) {
-          long long e = p * C + oct * 8;
-          gv[u] = *(const uint4*)(da + e);
-          yv[u] = *(const uint4*)(y + e);
-        }
-      }
+    for (long long p0 = pstart; p0 < P; p0 += stride * U) {
+      if (p0 != pstart) fetch(p0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         long long p = p0 + u * stride;
