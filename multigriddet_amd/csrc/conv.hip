@@ -2504,33 +2504,6 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   const unsigned dyt_a = lds_addr(dyt);
   // fused BN backward: this thread always stages the same 8 channels (chunk tid & 3)
   float bsc[8], bsh[8], bmu[8], biv[8], bm1[8], bm2[8];
-  if (FUSE_BN) {
-    if (tid < 64) {                                   // fold the R replicas: red[0..31] = sum dyh, red[32..63] = sum dyh*yhat
-      int which = tid >> 5, c = tid & 31;
-      float t = 0.f;
-      for (int r0 = 0; r0 < bn.R; r0 += 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = r0 + j < bn.R ? bn.sums[((long long)(r0 + j) * 2 + which) * 32 + c] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t += v[j];
-      }
-      red[tid] = t;
-      if (blockIdx.x == 0) {
-        if (which == 0 && bn.dbeta) bn.dbeta[c] += t;
-        if (which == 1 && bn.dgamma) bn.dgamma[c] += t;
-      }
-    }
-    __syncthreads();
-    const float invP = 1.0f / ((float)N * (float)H * (float)W);
-    const int c0 = (tid & 3) * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      bsc[j] = bn.scale[c0 + j]; bsh[j] = bn.shift[c0 + j]; bmu[j] = bn.mean[c0 + j]; biv[j] = bn.invstd[c0 + j];
-      bm1[j] = red[c0 + j] * invP; bm2[j] = red[32 + c0 + j] * invP;
-    }
-  }
-
   // software pipeline over the block's tiles: the next tile's global loads (image patch, dy or da + y) are issued into
   // registers right after the current tile is published to LDS and land while the matrix cores work on it
   constexpr int NPV = (PR * PCF + 255) / 256, NDV = TH * TW * 4 / 256;
@@ -2569,6 +2542,33 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     }
   };
   if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  if (FUSE_BN) {      // after the first tile's loads are in flight: the fold is a chain of dependent round trips
+    const int c0 = (tid & 3) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bsc[j] = bn.scale[c0 + j]; bsh[j] = bn.shift[c0 + j]; bmu[j] = bn.mean[c0 + j]; biv[j] = bn.invstd[c0 + j];
+    }
+    if (tid < 64) {                                   // fold the R replicas: red[0..31] = sum dyh, red[32..63] = sum dyh*yhat
+      int which = tid >> 5, c = tid & 31;
+      float t = 0.f;
+      for (int r0 = 0; r0 < bn.R; r0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = r0 + j < bn.R ? bn.sums[((long long)(r0 + j) * 2 + which) * 32 + c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += v[j];
+      }
+      red[tid] = t;
+      if (blockIdx.x == 0) {
+        if (which == 0 && bn.dbeta) bn.dbeta[c] += t;
+        if (which == 1 && bn.dgamma) bn.dgamma[c] += t;
+      }
+    }
+    __syncthreads();
+    const float invP = 1.0f / ((float)N * (float)H * (float)W);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bm1[j] = red[c0 + j] * invP; bm2[j] = red[32 + c0 + j] * invP; }
+  }
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     __syncthreads();                                  // previous tile's reads are done
 #pragma unroll
