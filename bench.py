@@ -194,9 +194,9 @@ def main():
     if prof:
         names = {"gemm128": "conv_gemm2_kernel<2,2,4,4,2> (128x128-tile bf16 MFMA gather-GEMM, two barrier-synchronous "
                             "blocks per CU: 3x3/1x1 conv forward + data gradient)",
-                 "gemm128pc": "conv_gemm6_kernel<2,2,4,4,3> (128x128-tile bf16 MFMA gather-GEMM, producer/consumer waves)",
+                 "gemm128pc": "conv_gemm6_kernel<2,2,4,4,4> (128x128-tile bf16 MFMA gather-GEMM, producer/consumer waves)",
                  "wgrad128": "conv_wgrad2_kernel<2,2,4,4> (128x128-tile bf16 MFMA weight gradient, per-tap blocks, split-K)"}
-        pmc_keys = {"gemm128": "conv_gemm2_kernel<2, 2, 4, 4, 2", "gemm128pc": "conv_gemm6_kernel<2, 2, 4, 4, 3",
+        pmc_keys = {"gemm128": "conv_gemm2_kernel<2, 2, 4, 4, 2", "gemm128pc": "conv_gemm6_kernel<2, 2, 4, 4",
                     "wgrad128": "conv_wgrad2_kernel<2, 2, 4, 4>"}
         step_ms = dt * 1e3 / args.steps
 

@@ -3061,7 +3061,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   if (d->Co_pad % 128 == 0 && nk >= 4 && !d->dst_f32 &&
       (variant == 9 || (variant == 3 && pc && (nblk128 <= 256 || (nblk128 <= 768 && nk >= 32))))) {
     static int ns6 = -1;
-    if (ns6 < 0) { const char* e = getenv("MGD_PC_STAGES"); ns6 = e ? atoi(e) : 3; }
+    if (ns6 < 0) { const char* e = getenv("MGD_PC_STAGES"); ns6 = e ? atoi(e) : 4; }   // 4 stages: equal to 3 alone, 0.2 % faster inside the step (latency under the side stream)
     if (ns6 == 4) launch_gemm6<2, 2, 4, 4, 4>(a, st); else launch_gemm6<2, 2, 4, 4, 3>(a, st);
     MGD_CHECK_LAUNCH("conv_gather_gemm(producer/consumer)");
     return MGD_OK;
