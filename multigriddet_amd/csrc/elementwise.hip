@@ -234,34 +234,43 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
       }
     }
   };
-  float sc[8], sh[8], mu[8], iv[8], m1[8], m2[8];
-  if (active) {
-    if (pstart < P) fetch(pstart);
+  float sc[8], sh[8], mu[8], iv[8], pa[8], pb[8];
+  if (active && pstart < P) fetch(pstart);
+  if (APPLY) {
+    // per-channel coefficients, computed once per block (thread t <-> channel blockIdx.y*256 + t) and shared through
+    // LDS:  dy = g * (z > 0 ? sc : sc*slope) - (pa + pb * y),  z = y*sc + sh,
+    //       pb = sc * m2 * invstd,  pa = sc * m1 - pb * mean   (m1, m2 = the two batch means; 0 when frozen)
+    __shared__ float prm[4][256];
+    int c = blockIdx.y * 256 + threadIdx.x;
+    float csc = 0.f, csh = 0.f, cpa = 0.f, cpb = 0.f;
+    if (c < C && threadIdx.x < CVB * 8) {
+      csc = scale[c];
+      csh = shift[c];
+      if (!frozen) {
+        const float cmu = smean[c], civ = sinv[c];
+        float sa = 0.f, sb = 0.f;
+        fold_replicas(sums, R, C, c, sa, sb);
+        if (blockIdx.x == 0) {
+          if (dbeta) dbeta[c] += sa;
+          if (dgamma) dgamma[c] += sb;
+        }
+        const float invP = 1.0f / (float)P;
+        cpb = csc * (sb * invP) * civ;
+        cpa = csc * (sa * invP) - cpb * cmu;
+      }
+    }
+    prm[0][threadIdx.x] = csc; prm[1][threadIdx.x] = csh; prm[2][threadIdx.x] = cpa; prm[3][threadIdx.x] = cpb;
+    __syncthreads();
+    if (active) {
+      int lo = (threadIdx.x % CVB) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sc[j] = prm[0][lo + j]; sh[j] = prm[1][lo + j]; pa[j] = prm[2][lo + j]; pb[j] = prm[3][lo + j]; }
+    }
+  } else if (active) {
     load8(scale + oct * 8, sc);
     load8(shift + oct * 8, sh);
     load8(smean + oct * 8, mu);
     load8(sinv + oct * 8, iv);
-  }
-  if (APPLY && !frozen) {
-    // fold the R replicas for this block's channel window: thread t <-> channel blockIdx.y*256 + t
-    int c = blockIdx.y * 256 + threadIdx.x;
-    float sa = 0.f, sb = 0.f;
-    if (c < C && threadIdx.x < CVB * 8) {
-      fold_replicas(sums, R, C, c, sa, sb);
-      if (blockIdx.x == 0) {
-        if (dbeta) dbeta[c] += sa;
-        if (dgamma) dgamma[c] += sb;
-      }
-    }
-    float invP = 1.0f / (float)P;
-    red[0][threadIdx.x] = sa * invP;
-    red[1][threadIdx.x] = sb * invP;
-    __syncthreads();
-  }
-  if (active && APPLY && !frozen) {
-    int lo = (threadIdx.x % CVB) * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { m1[j] = red[0][lo + j]; m2[j] = red[1][lo + j]; }
   }
   float s1[8], s2[8];
 #pragma unroll
@@ -281,10 +290,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
           for (int j = 0; j < 8; ++j) {
             float z = fmaf(v[j], sc[j], sh[j]);
             float d = z > 0.f ? g[j] : g[j] * slope;
-            float yh = (v[j] - mu[j]) * iv[j];
             if (APPLY) {
-              o[j] = frozen ? sc[j] * d : sc[j] * (d - m1[j] - yh * m2[j]);
+              o[j] = fmaf(sc[j], d, -fmaf(pb[j], v[j], pa[j]));
             } else {
+              float yh = (v[j] - mu[j]) * iv[j];
               s1[j] += d;
               s2[j] += d * yh;
             }
