@@ -90,3 +90,41 @@ def test_bucket_tiling():
     for (i0, b0, e0), (i1, b1, e1) in zip(bk, bk[1:]):
         assert e1 == b0 and i1 < i0
     assert sum(e - b for _, b, e in bk) == off
+
+
+def test_argument_validation_returns_einval_with_message():
+    """Bad arguments are rejected on the host before anything is launched (no GPU needed): MGD_EINVAL (-1) and a
+    thread-local message naming the entry point - the C-ABI's error convention (include/mgd_hip.h)."""
+    import ctypes as C
+    _lib = _build_if_needed()
+    lib = _lib.load()
+    cases = [
+        ("stem_wgrad_bn", lambda: lib.mgd_stem_wgrad_bn(None, None, None, None, None, None, None, None, 16, None, None,
+                                                        C.c_float(0.1), None, 1, 8, 8, None)),
+        ("stem_wgrad", lambda: lib.mgd_stem_wgrad(None, None, None, 1, 8, 8, None)),
+        ("stem_fwd", lambda: lib.mgd_stem_fwd(None, None, None, None, 0, 1, 8, 8, None)),
+        ("comm_init", lambda: lib.mgd_comm_init(None, 0, 1, None)),
+        ("comm_init", lambda: lib.mgd_comm_init(C.byref(C.c_void_p()), 3, 2, (C.c_ubyte * 128)())),
+        ("comm_allreduce_bucket", lambda: lib.mgd_comm_allreduce_bucket(None, None, C.c_int64(4), None)),
+        ("comm_unique_id", lambda: lib.mgd_comm_unique_id(None)),
+        ("pack_batch", lambda: lib.mgd_pack_weights_batch(None, 0, C.c_int64(0), None)),
+        ("wgrad", lambda: lib.mgd_conv_wgrad(None, None)),
+        ("conv", lambda: lib.mgd_conv_gather_gemm(None, None)),
+    ]
+    for name, call in cases:
+        assert call() == -1, name
+        assert name.encode() in lib.mgd_last_error(), (name, lib.mgd_last_error())
+    assert lib.mgd_comm_destroy(None) == 0          # destroying nothing is not an error
+
+
+def test_bucket_cut_points_follow_layer_boundaries():
+    """Gradient buckets are contiguous, tile the flat buffer from the END (the order backward finalises layers in) and
+    only ever start at a layer boundary."""
+    from multigriddet_amd.dp import make_buckets
+    offs = [0, 10, 30, 70, 150, 310]
+    bk = make_buckets(offs, 400, 100)
+    assert bk[0][2] == 400 and bk[-1][1] == 0
+    for (_, b, e), (_, b2, e2) in zip(bk, bk[1:]):
+        assert e2 == b and b2 < e2
+    assert all(b in offs for _, b, _ in bk)
+    assert all(e - b >= 100 for _, b, e in bk[:-1])
