@@ -2084,6 +2084,13 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
   }
 }
 
+// dy-tile chunk swizzle for eight consecutive pixel rows per 32-lane half: with 128-byte rows the row parity already
+// selects the bank half, the XOR supplies the other two bits; 256-byte rows all start on bank 0, the XOR supplies three.
+template <int RBO>
+__device__ __forceinline__ int w3_swz(int p) {
+  return RBO == 128 ? ((p >> 1) & 3) : (p & (RBO / 32 - 1));
+}
+
 // PPW = patch pieces (1 KiB LDS-DMA wave-instructions) per wave and stage: every wave issues exactly
 // OPW + PPW loads per stage, so the counted vmcnt waits are wave-uniform.
 // ROW = true: the form for Ci >= 128 (stride 1).  Nine taps of a 128 x 128 slice do not fit the register file, so a
@@ -2125,7 +2132,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
   for (int i = 0; i < OPW; ++i) {
     int p = (i * 4 + wave) * ORPI + lane / (RBO / 16);
     int o_s = lane % (RBO / 16);
-    int ch = (((o_s >> 1) ^ (ROW ? (p & (RBO / 32 - 1)) : tr_swz(p, RBO / 32))) << 1) | (o_s & 1);
+    int ch = (((o_s >> 1) ^ w3_swz<RBO>(p)) << 1) | (o_s & 1);
     int r = p / a.TW, c = p - r * a.TW;
     bool ok = r < a.R && co0 + ch * 8 < a.Co;
     dy_off[i] = (unsigned)((((long long)r * a.Wg + c) * a.Co + co0 + ch * 8) * 2);
@@ -2195,10 +2202,13 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
   for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      // ROW: a 32-lane half reads eight CONSECUTIVE pixels (the k index is summed over, any pixel <-> k-slot map
-      // that the two operands share is valid), which the 288-byte patch pitch spreads over all 64 banks
-      int p = ROW ? kk * 32 + 16 * (g >> 1) + 4 * (g & 1) + qq + 8 * h : kk * 32 + 8 * g + qq + 4 * h;
-      const int swz = ROW ? (p & (RBO / 32 - 1)) : tr_swz(p, RBO / 32);
+      // a 32-lane half reads eight CONSECUTIVE pixels (the k index is summed over, any pixel <-> k-slot map that the
+      // two operands share is valid): the padded patch pitch (96 / 160 / 288 bytes = 24 / 40 / 72 dwords, all = 8 mod
+      // 16) then spreads them over all 64 banks, and w3_swz does the same for the dy tile.  With the (0-3, 8-11) pixel
+      // groups of the plain tr-read layout every read of both operands was 2-way conflicted (SQ_LDS_BANK_CONFLICT =
+      // half of SQ_LDS_IDX_ACTIVE, profiles/r01_lds_conflicts.txt)
+      int p = kk * 32 + 16 * (g >> 1) + 4 * (g & 1) + qq + 8 * h;
+      const int swz = w3_swz<RBO>(p);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
         o_rd[kk][h][m] = p * RBO + (((wc * MT + m) ^ swz) * 32) + pl * 8;
