@@ -99,6 +99,45 @@ def cpu_baseline(size, batch):
                       f"batch {batch} (the benchmark batch), {cores} threads, after a 128x128 warm-up step; {dt:.2f} s"}
 
 
+def infer_bench(dev, size, steps=20, warmup=3):
+    """Second half of the BASELINE metric ("infer FPS+NMS"): forward on moving BatchNorm statistics + batched decode +
+    DIoU-NMS + top-100 + xyxy (reference inference_engine.py:98-140 -> postprocess/multigrid_decode.py:237-345), synthetic
+    608x608 batches resident in HBM, random-init weights.  Outside the train-step timed region; one sub-record per
+    (batch, fold_bn).  confidence 0.008 so that the random-init heads keep ~100 detections per image and NMS does real
+    work (at the reference's 0.1 nothing survives the filter on random weights)."""
+    from multigriddet_amd.models import build_multigriddet_darknet
+    from multigriddet_amd.postprocess import MultiGridDecoder
+    model, _ = build_multigriddet_darknet(input_shape=(size, size, 3), num_classes=80)
+    dec = MultiGridDecoder(coco_anchors(), 80, (size, size))
+    kw = dict(max_boxes=100, confidence=0.008, nms_threshold=0.45, nms_method="diou")
+    runs = []
+    for batch in (16, 1):
+        img = torch.from_numpy(np.random.default_rng(0).random((batch, size, size, 3), dtype=np.float32)).to(dev)
+        shapes = [(480, 640)] * batch
+        for fold in (False, True):
+            model.fold_bn(fold)
+            for _ in range(warmup):
+                r = dec.postprocess_batch(model(img, training=False), shapes, **kw)
+            torch.cuda.synchronize()
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                e0.record()
+                outs = model(img, training=False)
+                e1.record()
+                r = dec.postprocess_batch(outs, shapes, **kw)
+                e2.record()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            runs.append({"batch": batch, "fold_bn": fold, "images_per_sec": round(batch * steps / dt, 1),
+                         "ms_per_batch": round(1e3 * dt / steps, 3), "forward_ms": round(e0.elapsed_time(e1), 3),
+                         "decode_nms_ms": round(e1.elapsed_time(e2), 3), "detections_last_batch": int(r[3].sum())})
+    model.fold_bn(False)
+    return {"metric": "inference images/sec incl. decode + DIoU-NMS", "size": size, "steps": steps, "warmup": warmup,
+            "nms": "diou", "confidence": 0.008, "max_boxes": 100, "dtype": "bf16",
+            "data": "synthetic, random-init weights, moving BN statistics", "runs": runs}
+
+
 def pmc_traffic(prefix="conv_gemm2_kernel<2, 2, 4, 4, 2"):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (collected in separate
     rocprofv3 --pmc passes of this same command; FETCH_SIZE x2 on gfx950 + WRITE_SIZE); (None, reason) if absent."""
@@ -121,6 +160,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-infer", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,6 +273,12 @@ def main():
                    "train_tflops_per_gpu": round(ips / world * 3 * FLOP_PER_IMAGE_FWD * (args.size / 608) ** 2 / 1e12, 1)},
         "roofline": roof,
     }
+    if world == 1 and not args.no_infer:
+        del ts, net
+        torch.cuda.empty_cache()
+        out["infer"] = infer_bench(dev, args.size)
+    else:
+        out["infer"] = None
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.batch)
     else:

@@ -47,6 +47,9 @@ int mgd_version(void);
  * `wpk` is a packed bf16 weight image [Co_pad][K_pad] produced by mgd_pack_weights.
  * Optional epilogues: per-channel sum / sum-of-squares of the (bf16-rounded) result into
  * `stats[(block % stats_replicas)][2][Co]` for training-mode BatchNorm; fp32 output.
+ * Limits (MGD_EINVAL otherwise): N*Hg*Wg < 2^31 pixels; the kernels address `src` and `wpk` with 32-bit byte
+ * offsets from a scalar base, so N*Hs*Ws*Ci*2 < 2^32 and Co_pad*K_pad*2 < 2^32 (4 GiB per operand; at 608x608 the
+ * 64-channel 304x304 maps reach that at N ~ 360 images per call).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct mgd_conv_desc {
   const void* src;      /* bf16 [N, Hs, Ws, Ci]                                   */

@@ -47,234 +47,10 @@ struct GemmArgs {
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * ROWB + ((kc ^ (row & 7)) << 4); }
 
-template <int WC, int WP, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_gather_gemm_kernel(GemmArgs a) {
-  constexpr int BNC = WC * MT * 16;  // output channels per block
-  constexpr int BMP = WP * NT * 16;  // pixels per block
-  static_assert(WC * WP == 4, "4 waves");
-  static_assert(BMP == 128, "pixel tile fixed at 128");
-  constexpr int WCH = BNC * 8 / 256;  // weight chunks per thread
-  constexpr int XCH = BMP * 8 / 256;  // pixel chunks per thread (4)
-  constexpr int STAGE = (BNC + BMP) * ROWB;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ long long row_dst[BMP];  // destination element offset of each pixel row (-1 = none)
-  __shared__ float colred[2 * 128];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wc = wave / WP, wp = wave % WP;
-
-  const int L = xcd_remap(blockIdx.x, a.nblk);
-  const int tc = L % a.tilesC, tp = L / a.tilesC;
-  const int co0 = tc * BNC;
-  const int pix0 = tp * BMP;
-
-  // ---- per-row destination offsets (used by the epilogue)
-  if (tid < BMP) {
-    int m = pix0 + tid;
-    long long off = -1;
-    if (m < a.M) {
-      int hw = a.Hg * a.Wg;
-      int n = m / hw, rem = m - n * hw;
-      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
-      int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
-      off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
-    }
-    row_dst[tid] = off;
-  }
-
-  // ---- per-thread gather state: XCH rows, one k-chunk column
-  const int kc = tid & 7;
-  long long xbase[XCH];
-  int hs0[XCH], ws0[XCH];
-#pragma unroll
-  for (int i = 0; i < XCH; ++i) {
-    int r = (tid >> 3) + 32 * i;
-    int m = pix0 + r;
-    if (m < a.M) {
-      int hw = a.Hg * a.Wg;
-      int n = m / hw, rem = m - n * hw;
-      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
-      hs0[i] = ig * a.in_stride;
-      ws0[i] = jg * a.in_stride;
-      xbase[i] = (((long long)n * a.Hs + hs0[i]) * a.Ws + ws0[i]) * a.Ci;
-    } else {
-      hs0[i] = -(1 << 20);
-      ws0[i] = -(1 << 20);
-      xbase[i] = 0;
-    }
-  }
-  int tap = (kc * 8) / a.Ci;
-  int cch = (kc * 8) - tap * a.Ci;
-
-  const bf16_t* wrow[WCH];
-#pragma unroll
-  for (int i = 0; i < WCH; ++i) {
-    int q = tid + 256 * i;
-    wrow[i] = a.wpk + (long long)(co0 + (q >> 3)) * a.K_pad + (q & 7) * 8;
-  }
-
-  uint4 wreg[WCH], xreg[XCH];
-  auto load_global = [&](int ks) {
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) wreg[i] = *(const uint4*)(wrow[i] + ks * BK);
-    int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
-    int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
-    bool tv = tap < a.ntaps;
-    long long toff = ((long long)dh * a.Ws + dw) * a.Ci + cch;
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-      bool v = tv && (unsigned)(hs0[i] + dh) < (unsigned)a.Hs && (unsigned)(ws0[i] + dw) < (unsigned)a.Ws;
-      uint4 z = make_uint4(0, 0, 0, 0);
-      if (v) z = *(const uint4*)(a.src + xbase[i] + toff);
-      xreg[i] = z;
-    }
-    cch += BK;
-    while (cch >= a.Ci) {
-      cch -= a.Ci;
-      ++tap;
-    }
-  };
-  auto write_lds = [&](int buf) {
-    unsigned char* wb = smem + buf * STAGE;
-    unsigned char* xb = wb + BNC * ROWB;
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-      int q = tid + 256 * i;
-      *(uint4*)(wb + lds_off(q >> 3, q & 7)) = wreg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-      int r = (tid >> 3) + 32 * i;
-      *(uint4*)(xb + lds_off(r, kc)) = xreg[i];
-    }
-  };
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = a.K_pad / BK;
-  load_global(0);
-  write_lds(0);
-  __syncthreads();
-
-  const int fr = lane & 15, fq = lane >> 4;
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) load_global(ks + 1);
-    const unsigned char* wb = smem + buf * STAGE;
-    const unsigned char* xb = wb + BNC * ROWB;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 wf[MT], xf[NT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(wb + lds_off((wc * MT + m) * 16 + fr, kk * 4 + fq));
-#pragma unroll
-      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(xb + lds_off((wp * NT + n) * 16 + fr, kk * 4 + fq));
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
-    }
-    if (ks + 1 < nk) write_lds(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: accumulators -> LDS [pixel][channel] -> coalesced NHWC rows
-  const int esz = a.dst_f32 ? 4 : 2;
-  const int EROW = BNC * esz + 16;
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    int cl = (wc * MT + m) * 16 + fq * 4;  // first of 4 consecutive channels
-    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    if (a.bias) {
-      int c = co0 + cl;
-      if (c + 3 < a.Co) { b0 = a.bias[c]; b1 = a.bias[c + 1]; b2 = a.bias[c + 2]; b3 = a.bias[c + 3]; }
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      int pl = (wp * NT + n) * 16 + fr;
-      f32x4 v = acc[m][n];
-      v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
-      if (a.act_slope != 0.f) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * a.act_slope;
-      }
-      if (a.dst_f32) {
-        *(f32x4*)(smem + pl * EROW + cl * 4) = v;
-      } else {
-        uint2 p;
-        p.x = pack2bf(v[0], v[1]);
-        p.y = pack2bf(v[2], v[3]);
-        *(uint2*)(smem + pl * EROW + cl * 2) = p;
-      }
-    }
-  }
-  __syncthreads();
-
-  const int rows_valid = min(BMP, a.M - pix0);
-  if (a.stats && !a.dst_f32) {
-    // column sums of the bf16-rounded tile: thread = (column pair, row group), then LDS, then
-    // 2*BNC well-shaped global atomics per block into one of `stats_replicas` copies.
-    constexpr int NCP = BNC / 2, RG = 256 / NCP, RPG = BMP / RG;
-    if (tid < 2 * BNC) colred[tid] = 0.f;
-    __syncthreads();
-    int cp = tid % NCP, rg = tid / NCP;
-    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-    int rend = min(rows_valid, (rg + 1) * RPG);
-    for (int r = rg * RPG; r < rend; ++r) {
-      uint32_t u = *(const uint32_t*)(smem + r * EROW + cp * 4);
-      float v0 = __uint_as_float(u << 16), v1 = __uint_as_float(u & 0xffff0000u);
-      s0 += v0; s1 += v1; q0 += v0 * v0; q1 += v1 * v1;
-    }
-    atomicAdd(&colred[2 * cp], s0);
-    atomicAdd(&colred[2 * cp + 1], s1);
-    atomicAdd(&colred[BNC + 2 * cp], q0);
-    atomicAdd(&colred[BNC + 2 * cp + 1], q1);
-    __syncthreads();
-    if (tid < 2 * BNC) {
-      int which = tid / BNC, col = tid - which * BNC;
-      if (co0 + col < a.Co) {
-        int rep = blockIdx.x % a.stats_replicas;
-        atomicAdd(a.stats + ((long long)rep * 2 + which) * a.Co + co0 + col, colred[tid]);
-      }
-    }
-  }
-  const int CPR = BNC * esz / 16;  // 16-byte chunks per row
-  for (int q = tid; q < BMP * CPR; q += 256) {
-    int r = q / CPR, ch = q - r * CPR;
-    long long off = row_dst[r];
-    int c = co0 + ch * (16 / esz);
-    if (off < 0 || c >= a.Co) continue;
-    uint4 v = *(const uint4*)(smem + r * EROW + ch * 16);
-    if (a.dst_f32) {
-      *(uint4*)((float*)a.dst + off + c) = v;
-    } else {
-      if (a.addend) {
-        uint4 ad = *(const uint4*)(a.addend + off + c);
-        float f[8], g[8];
-        unpack8(v, f);
-        unpack8(ad, g);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] += g[j];
-        v = pack8(f);
-      }
-      *(uint4*)((bf16_t*)a.dst + off + c) = v;
-    }
-  }
-}
-
-
 // ------------------------------------------------------------------------------------------------
-// v2: LDS-DMA (global_load_lds) staging into an NST-deep LDS ring with counted vmcnt and one raw
-// s_barrier per K-step - the loads of NST-1 stages stay in flight across barriers, which is what hides
-// the L2/HBM latency the register-staged kernel above exposes (it measured ~2 us per K-step).
+// Gather-GEMM: LDS-DMA (global_load_lds) staging into an NST-deep LDS ring with counted vmcnt and one raw
+// s_barrier per K-step - the loads of NST-1 stages stay in flight across barriers, which hides the L2/HBM
+// latency a register-staged loop exposes (~2 us per K-step).
 // LDS image per stage: W tile [BNC][64 bf16] then X tile [128][64 bf16], rows of 128 B, the 16-byte
 // chunk kc of row r stored at slot kc ^ (r & 7).  LDS-DMA writes lane-linear (base + lane*16), so the
 // swizzle is applied on the per-lane SOURCE address; zero padding comes from a zero page in HBM.
@@ -827,173 +603,6 @@ struct GemmEpilogue {
 };
 
 // ------------------------------------------------------------------------------------------------
-// v4, "row-shift" form of the 3x3 stride-1 gather-GEMM (forward and stride-1 data gradient).  The three taps
-// (dh, -1), (dh, 0), (dh, +1) of one 64-channel chunk gather the SAME 128 flattened pixels shifted by one pixel,
-// so the pixel tile is staged once per (dh, chunk) as 130 rows (pixels pix0-1 .. pix0+128 of input row h+dh)
-// and the three K-steps read it at row offsets 0/1/2: LDS-DMA bytes per K-step fall from 32 KB to 21.7 KB
-// (the kernel is bound by the per-CU L2->LDS rate, not by MFMA).  Lanes whose pixel sits on the left/right
-// image border read a zero row for the dw = -1 / +1 step instead.  Weight tiles keep the 2-stage ring of v2.
-// LDS: W ring 2 x BNC rows | X0 | X1 (137 rows each: 136 DMA rows + 1 zero row) | row_dst.
-template <int WC, int WP, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_gemm4_kernel(GemmArgs a) {
-  using Epi = GemmEpilogue<WC, WP, MT, NT>;
-  constexpr int BNC = WC * MT * 16;
-  constexpr int BMP = WP * NT * 16;
-  static_assert(WC * WP == 4 && BMP == 128, "4 waves, 128-pixel tile");
-  constexpr int WCH = BNC / 32;                 // weight LDS-DMA pieces per wave per K-step
-  constexpr int WST = BNC * ROWB;               // bytes per weight stage
-  constexpr int XROWS = 137, XZ = 136;          // pixel-buffer rows, index of the zero row
-  constexpr int XBUF = XROWS * ROWB;
-  constexpr int XP = 17;                        // 1-KiB pieces per pixel buffer (rows 0..135)
-  constexpr int RING = 2 * WST + 2 * XBUF;
-  constexpr int EPI_MAX = BMP * (BNC * 4 + 16);
-  constexpr int AUX = RING > EPI_MAX ? RING : EPI_MAX;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  long long* row_dst = (long long*)(smem + AUX);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wc = wave / WP, wp = wave % WP;
-  const int L = xcd_remap(blockIdx.x, a.nblk);
-  const int tc = L % a.tilesC, tp = L / a.tilesC;
-  const int co0 = tc * BNC;
-  const int pix0 = tp * BMP;
-  const int hw = a.Hg * a.Wg;
-
-  if (tid < BMP) {
-    int m = pix0 + tid;
-    long long off = -1;
-    if (m < a.M) {
-      int n = m / hw, rem = m - n * hw;
-      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
-      off = (((long long)n * a.Hd + ig) * a.Wd + jg) * a.Co;
-    }
-    row_dst[tid] = off;
-  }
-  if (tid < 16) {   // the zero rows
-    *(uint4*)(smem + 2 * WST + XZ * ROWB + (tid & 7) * 16 + (tid >> 3) * XBUF) = make_uint4(0, 0, 0, 0);
-  }
-  Epi epi;
-  epi.prefetch(a, row_dst, co0, tid);
-
-  // ---- weight pieces: thread -> slot (tid & 7) of rows (tid >> 3) + 32 i, source chunk kc = slot ^ (row & 7)
-  const int rlo = tid >> 3;
-  const int kc = (tid & 7) ^ (rlo & 7);
-  unsigned woff[WCH];
-#pragma unroll
-  for (int i = 0; i < WCH; ++i) woff[i] = (unsigned)(((long long)(co0 + rlo + 32 * i) * a.K_pad + kc * 8) * 2);
-  const char* wbase = (const char*)a.wpk;
-
-  // ---- pixel pieces: piece p (rows 8p..8p+7 of the buffer, row r <-> flattened pixel pix0 - 1 + r) is issued by
-  // wave p % 4; per piece a byte offset of the un-shifted pixel and a 3-bit mask "input row h+dh exists"
-  constexpr int XPW = (XP + 3) / 4;             // pieces per wave (5, the last one only on wave 0)
-  unsigned xoff[XPW], xmask[XPW];
-#pragma unroll
-  for (int j = 0; j < XPW; ++j) {
-    int p = j * 4 + wave;
-    int r = p * 8 + (lane >> 3);
-    int m = pix0 - 1 + r;
-    xoff[j] = 0; xmask[j] = 0;
-    if (p < XP && r < 130 && m >= 0 && m < a.M) {
-      int n = m / hw, rem = m - n * hw;
-      int ig = rem / a.Wg;
-      int slot = lane & 7;
-      xoff[j] = (unsigned)(((long long)m * a.Ci + ((slot ^ (r & 7)) * 8)) * 2);
-      xmask[j] = (ig > 0 ? 1u : 0u) | 2u | (ig + 1 < a.Hg ? 4u : 0u);
-    }
-  }
-  const char* xbase = (const char*)a.src;
-  const void* zero = (const void*)g_zero_page;
-  const int rowbytes = a.Wg * a.Ci * 2;
-  const int nch = a.Ci / BK;                    // 64-channel chunks
-  const int nbt = 3 * nch;                      // pixel tiles: (dh, chunk)
-  const int nsteps = 3 * nbt;
-
-  auto issue_w = [&](int step, int buf) {       // step = (dh*nch + cc)*3 + dwi
-    int bt = step / 3, dwi = step - bt * 3;
-    int dhi = bt / nch, cc = bt - dhi * nch;
-    unsigned k0 = (unsigned)(((dhi * 3 + dwi) * a.Ci + cc * BK) * 2);
-    unsigned char* wb = smem + buf * WST + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) glds16(wbase + woff[i] + k0, wb + i * (32 * ROWB));
-  };
-  auto issue_x = [&](int bt, int part) {        // third `part` (0..2) of pixel tile bt into buffer bt & 1
-    int dhi = bt / nch, cc = bt - dhi * nch;
-    long long shift = (long long)(dhi - 1) * rowbytes + cc * (BK * 2);
-    unsigned char* xb = smem + 2 * WST + (bt & 1) * XBUF;
-#pragma unroll
-    for (int j = 0; j < XPW; ++j) {
-      int p = j * 4 + wave;
-      if (p < XP && p / 6 == part) {
-        bool v = (xmask[j] >> dhi) & 1u;
-        const void* g = v ? (const void*)(xbase + xoff[j] + shift) : zero;
-        glds16(g, xb + p * 1024);
-      }
-    }
-  };
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int fr = lane & 15, fq = lane >> 4;
-  int wro[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) wro[m] = lds_off((wc * MT + m) * 16 + fr, fq);
-  // my pixels: row in the buffer for dw = 0 is pl + 1; border flags select the zero row for dw = -1 / +1
-  int prow[NT];
-  unsigned bflag = 0;
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    int pl = (wp * NT + n) * 16 + fr;
-    prow[n] = pl + 1;
-    int m = pix0 + pl;
-    int jg = m % a.Wg;
-    if (jg == 0) bflag |= 1u << (2 * n);
-    if (jg == a.Wg - 1) bflag |= 2u << (2 * n);
-  }
-
-  // prologue: first pixel tile (all three parts) and the first weight stage
-  issue_x(0, 0); issue_x(0, 1); issue_x(0, 2);
-  issue_w(0, 0);
-  int bt = 0, dwi = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (s + 1 < nsteps) issue_w(s + 1, (s + 1) & 1);
-    if (bt + 1 < nbt) issue_x(bt + 1, dwi);
-    const unsigned char* wb = smem + (s & 1) * WST;
-    const unsigned char* xb = smem + 2 * WST + (bt & 1) * XBUF;
-    int xro[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      int r = prow[n] + dwi - 1;
-      bool z = (dwi == 0 && ((bflag >> (2 * n)) & 1u)) || (dwi == 2 && ((bflag >> (2 * n)) & 2u));
-      r = z ? XZ : r;
-      xro[n] = r * ROWB + ((fq ^ (r & 7)) << 4);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 wf[MT], xf[NT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(wb + (wro[m] ^ (kk << 6)));
-#pragma unroll
-      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(xb + (xro[n] ^ (kk << 6)));
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
-    }
-    if (++dwi == 3) { dwi = 0; ++bt; }
-  }
-  __syncthreads();
-  epi.run(a, acc, smem, row_dst, co0, tid);
-}
-
-// ------------------------------------------------------------------------------------------------
 // v6: producer / consumer form of the gather-GEMM.  The v2 K-loop is bound by LDS-DMA issue + landing latency and the
 // block barrier per K-step (MGD_DBG=2 stamps: a wave spends 24 % of a K-step issuing its 8 LDS-DMA pieces, 42 %
 // waiting for the stage, 10 % in the barrier, 24 % on fragment reads + MFMA).  Here a block is 8 waves: waves 0-3
@@ -1413,266 +1022,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_dgrad2_kernel(Dgrad2Args d)
   epi.flush(a, el, 0, tid);
 }
 
-template <int WC, int WP, int MT, int NT, int NST>
-__global__ __launch_bounds__(64 * WC * WP) void conv_gemm3_kernel(GemmArgs a) {
-  // BK = 32 variant: tile rows are 64 B (4 chunks of 16 B), chunk c of row r stored at slot c ^ g((r>>2)&3)
-  // with g = {0,3,2,1} (conflict-free ds_read_b128 for the 16x16x32 fragment pattern); one LDS-DMA
-  // wave-instruction covers 16 rows.  Bigger block tile (256 pixels) and 128x64 wave tiles cut the
-  // LDS-DMA bytes per FLOP by 25 % and the fragment reads per MFMA from 16/32 to 12/32.
-  constexpr int BK = 32;
-  constexpr int ROWB = 64;
-  constexpr int BNC = WC * MT * 16;
-  constexpr int BMP = WP * NT * 16;
-  constexpr int NTHR = 64 * WC * WP;      // 4 waves (128-pixel tile, 2 blocks/CU) or 8 waves (256-pixel tile)
-  constexpr int RPR = NTHR / 4;            // tile rows covered by one LDS-DMA round of the block
-  static_assert(BMP % RPR == 0 && BNC % RPR == 0, "tile/threads");
-  constexpr int WCH = BNC / RPR;  // weight glds per thread per stage
-  constexpr int XCH = BMP / RPR;  // pixel glds per thread per stage
-  constexpr int LPS = WCH + XCH;  // loads per stage per wave
-  constexpr int STAGE = (BNC + BMP) * ROWB;
-  constexpr int EPI_MAX = BMP * (BNC * 2 + 16);    // bf16 epilogue tile only (fp32 output is not dispatched here)
-  constexpr int AUX = NST * STAGE > EPI_MAX ? NST * STAGE : EPI_MAX;   // then row_dst (BMP x 8 B) + colred (256 x 4 B)
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  long long* row_dst = (long long*)(smem + AUX);
-  float* colred = (float*)(smem + AUX + BMP * 8);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wc = wave / WP, wp = wave % WP;
-
-  const int L = xcd_remap(blockIdx.x, a.nblk);
-  const int tc = L % a.tilesC, tp = L / a.tilesC;
-  const int co0 = tc * BNC;
-  const int pix0 = tp * BMP;
-
-  if (tid < BMP) {
-    int m = pix0 + tid;
-    long long off = -1;
-    if (m < a.M) {
-      int hw = a.Hg * a.Wg;
-      int n = m / hw, rem = m - n * hw;
-      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
-      int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
-      off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
-    }
-    row_dst[tid] = off;
-  }
-
-  // thread -> LDS slot (tid & 7) of rows (tid >> 3) + RPR i ; source chunk kc = slot ^ (row & 7).
-  // Address generation is kept off the critical path (the first version spent 5.7 VALU instructions
-  // per MFMA on it): per row a 32-bit byte offset and a 9-bit tap-validity mask are computed once; per
-  // K-step a load costs a mask test, a select and an add, with the tensor base in SGPRs.  Out-of-image
-  // taps load from offset 0 (any valid address) and the owning lane overwrites its 16-byte LDS slot
-  // with zeros once its own DMA has landed (before the barrier that publishes the stage).
-  const int rlo = tid >> 2;
-  const int kc = (tid & 3) ^ ((4 - ((rlo >> 2) & 3)) & 3);
-  unsigned xoff[XCH];
-  unsigned vmask[XCH];
-#pragma unroll
-  for (int i = 0; i < XCH; ++i) {
-    int m = pix0 + rlo + RPR * i;
-    xoff[i] = 0;
-    vmask[i] = 0;
-    if (m < a.M) {
-      int hw = a.Hg * a.Wg;
-      int n = m / hw, rem = m - n * hw;
-      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
-      int hs = ig * a.in_stride, ws = jg * a.in_stride;
-      xoff[i] = (unsigned)(((((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci) * 2);
-      for (int t = 0; t < a.ntaps; ++t) {
-        int dh = (int)((a.tapcode >> (4 * t)) & 3) - 1, dw = (int)((a.tapcode >> (4 * t + 2)) & 3) - 1;
-        if ((unsigned)(hs + dh) < (unsigned)a.Hs && (unsigned)(ws + dw) < (unsigned)a.Ws) vmask[i] |= 1u << t;
-      }
-    }
-  }
-  int tap = (kc * 8) / a.Ci;
-  int cch = (kc * 8) - tap * a.Ci;
-  unsigned woff[WCH];
-#pragma unroll
-  for (int i = 0; i < WCH; ++i) woff[i] = (unsigned)(((long long)(co0 + rlo + RPR * i) * a.K_pad + kc * 8) * 2);
-  const char* xbase = (const char*)a.src;
-  const char* wbase = (const char*)a.wpk;
-  // my LDS slots (byte offsets inside a stage) for the zero fix-up
-
-  unsigned inv_next = 0;
-  auto issue = [&](int ks, int buf) {
-    unsigned char* wb = smem + buf * STAGE + wave * 1024;          // 16 rows x 64 B per wave-instruction
-    unsigned char* xb = smem + buf * STAGE + BNC * ROWB + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < WCH; ++i)
-      glds16(wbase + ((a.dbg & 1) ? 0u : woff[i] + (unsigned)ks * (BK * 2)), wb + i * (RPR * ROWB));
-    int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
-    int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
-    int toff = ((dh * a.Ws + dw) * a.Ci + cch) * 2;
-    inv_next = 0;
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-      bool v = (vmask[i] >> tap) & 1u;
-      unsigned off = v ? xoff[i] + (unsigned)toff : 0u;
-      if (a.dbg & 1) off = 0u;
-      if (!v) inv_next |= 1u << i;
-      glds16(xbase + off, xb + i * (RPR * ROWB));
-    }
-    cch += BK;
-    while (cch >= a.Ci) {
-      cch -= a.Ci;
-      ++tap;
-    }
-  };
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = a.K_pad / BK;
-  // ring bookkeeping of the zero fix-up masks: stage s issued -> inv[s % NST]
-  unsigned inv[NST];
-#pragma unroll
-  for (int s = 0; s < NST; ++s) inv[s] = 0;
-#pragma unroll
-  for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) { issue(s, s); inv[s] = inv_next; }
-
-  const int fr = lane & 15, fq = lane >> 4;
-  // fragment read offsets inside a stage (k-half kk flips bit 6 of the byte offset)
-  int wro[MT], xro[NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    int r = (wc * MT + m) * 16 + fr;
-    wro[m] = r * ROWB + ((fq ^ ((4 - ((r >> 2) & 3)) & 3)) << 4);
-  }
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    int r = (wp * NT + n) * 16 + fr;
-    xro[n] = BNC * ROWB + r * ROWB + ((fq ^ ((4 - ((r >> 2) & 3)) & 3)) << 4);
-  }
-  const int zslot = BNC * ROWB + (rlo * ROWB) + (tid & 3) * 16;   // + i * RPR*ROWB : my X slots
-
-  for (int ks = 0; ks < nk; ++ks) {
-    int pending = min(NST - 2, nk - 1 - ks);
-    if (NST >= 4 && pending >= 2) wait_vmcnt<2 * LPS>();
-    else if (NST >= 3 && pending == 1) wait_vmcnt<LPS>();
-    else wait_vmcnt<0>();
-    const int cur = ks % NST;
-    unsigned char* sb = smem + cur * STAGE;
-    unsigned invc = 0;
-#pragma unroll
-    for (int s = 0; s < NST; ++s)
-      if (s == cur) invc = inv[s];
-    if (invc) {
-#pragma unroll
-      for (int i = 0; i < XCH; ++i)
-        if (invc & (1u << i)) *(uint4*)(sb + zslot + i * (RPR * ROWB)) = make_uint4(0, 0, 0, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (ks + NST - 1 < nk) {
-      issue(ks + NST - 1, (ks + NST - 1) % NST);
-#pragma unroll
-      for (int s = 0; s < NST; ++s)
-        if (s == (ks + NST - 1) % NST) inv[s] = inv_next;
-    }
-    {
-      bf16x8 wf[MT], xf[NT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(sb + wro[m]);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + xro[n]);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
-    }
-  }
-  __syncthreads();
-
-  // ---- epilogue (same as v1)
-  const int esz = a.dst_f32 ? 4 : 2;
-  const int EROW = BNC * esz + 16;
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    int cl = (wc * MT + m) * 16 + fq * 4;
-    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    if (a.bias) {
-      int c = co0 + cl;
-      if (c + 3 < a.Co) { b0 = a.bias[c]; b1 = a.bias[c + 1]; b2 = a.bias[c + 2]; b3 = a.bias[c + 3]; }
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      int pl = (wp * NT + n) * 16 + fr;
-      f32x4 v = acc[m][n];
-      v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
-      if (a.act_slope != 0.f) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * a.act_slope;
-      }
-      if (a.dst_f32) {
-        *(f32x4*)(smem + pl * EROW + cl * 4) = v;
-      } else {
-        uint2 p;
-        p.x = pack2bf(v[0], v[1]);
-        p.y = pack2bf(v[2], v[3]);
-        *(uint2*)(smem + pl * EROW + cl * 2) = p;
-      }
-    }
-  }
-  __syncthreads();
-  const int rows_valid = min(BMP, a.M - pix0);
-  if (a.stats && !a.dst_f32) {
-    constexpr int NCP = BNC / 2, RG = NTHR / NCP, RPG = BMP / RG;
-    if (tid < 2 * BNC) colred[tid] = 0.f;
-    __syncthreads();
-    int cp = tid % NCP, rg = tid / NCP;
-    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-    int rend = min(rows_valid, (rg + 1) * RPG);
-    for (int r = rg * RPG; r < rend; ++r) {
-      uint32_t u = *(const uint32_t*)(smem + r * EROW + cp * 4);
-      float v0 = __uint_as_float(u << 16), v1 = __uint_as_float(u & 0xffff0000u);
-      s0 += v0; s1 += v1; q0 += v0 * v0; q1 += v1 * v1;
-    }
-    atomicAdd(&colred[2 * cp], s0);
-    atomicAdd(&colred[2 * cp + 1], s1);
-    atomicAdd(&colred[BNC + 2 * cp], q0);
-    atomicAdd(&colred[BNC + 2 * cp + 1], q1);
-    __syncthreads();
-    if (tid < 2 * BNC) {
-      int which = tid / BNC, col = tid - which * BNC;
-      if (co0 + col < a.Co) {
-        int rep = blockIdx.x % a.stats_replicas;
-        atomicAdd(a.stats + ((long long)rep * 2 + which) * a.Co + co0 + col, colred[tid]);
-      }
-    }
-  }
-  const int CPR = BNC * esz / 16;
-  for (int q = tid; q < BMP * CPR; q += NTHR) {
-    int r = q / CPR, ch = q - r * CPR;
-    long long off = row_dst[r];
-    int c = co0 + ch * (16 / esz);
-    if (off < 0 || c >= a.Co) continue;
-    uint4 v = *(const uint4*)(smem + r * EROW + ch * 16);
-    if (a.dst_f32) {
-      *(uint4*)((float*)a.dst + off + c) = v;
-    } else {
-      if (a.addend) {
-        uint4 ad = *(const uint4*)(a.addend + off + c);
-        float f[8], g[8];
-        unpack8(v, f);
-        unpack8(ad, g);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] += g[j];
-        v = pack8(f);
-      }
-      *(uint4*)((bf16_t*)a.dst + off + c) = v;
-    }
-  }
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // Weight gradient.  dW[co][tap][ci] += sum_p dy[p][co] * src[p (+) tap][ci]
 // LDS tiles are [pixel][channel] exactly as they come from NHWC memory; MFMA fragments need
@@ -1698,163 +1047,6 @@ __device__ __forceinline__ int tr_swz(int row, int nchunk32) {
 __device__ __forceinline__ s16x4 ds_read_tr16(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
-
-template <int WC, int WI, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
-  constexpr int BCO = WC * MT * 16;
-  constexpr int BCI = WI * NT * 16;
-  static_assert(WC * WI == 4, "4 waves");
-  constexpr int RBO = BCO * 2, RBI = BCI * 2;      // row bytes
-  constexpr int CO_CPR = BCO / 8, CI_CPR = BCI / 8;  // 16-byte chunks per row
-  constexpr int OCH = 64 * CO_CPR / 256, ICH = 64 * CI_CPR / 256;  // chunks per thread
-  static_assert(OCH >= 1 && ICH >= 1, "tile too small");
-  constexpr int STAGE = 64 * (RBO + RBI);
-  constexpr int EROW = (BCI + 4) * 4;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wc = wave / WI, wi = wave % WI;
-
-  int b = blockIdx.x;
-  const int tco = b % a.tilesCo; b /= a.tilesCo;
-  const int tci = b % a.tilesCi; b /= a.tilesCi;
-  const int tap = b % a.ntaps;
-  const int split = b / a.ntaps;
-  const int co0 = tco * BCO, ci0 = tci * BCI;
-  const int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
-  const int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
-  const int pbeg = split * a.chunk;
-  const int pend = min(a.P, pbeg + a.chunk);
-  const int nk = (pend - pbeg + 63) / 64;
-
-  uint4 oreg[OCH], ireg[ICH];
-  auto load_global = [&](int ks) {
-    const int p0 = pbeg + ks * 64;
-#pragma unroll
-    for (int i = 0; i < OCH; ++i) {
-      int q = tid + 256 * i;
-      int r = q / CO_CPR, ch = q - r * CO_CPR;
-      int p = p0 + r, c = co0 + ch * 8;
-      uint4 z = make_uint4(0, 0, 0, 0);
-      if (p < pend && c < a.Co) z = *(const uint4*)(a.dy + (long long)p * a.Co + c);
-      oreg[i] = z;
-    }
-#pragma unroll
-    for (int i = 0; i < ICH; ++i) {
-      int q = tid + 256 * i;
-      int r = q / CI_CPR, ch = q - r * CI_CPR;
-      int p = p0 + r, c = ci0 + ch * 8;
-      uint4 z = make_uint4(0, 0, 0, 0);
-      if (p < pend && c < a.Ci) {
-        const int hw = a.Hg * a.Wg;
-        int n = (int)((float)p * a.rcp_hw);
-        int rem = p - n * hw;
-        while (rem < 0) { --n; rem += hw; }
-        while (rem >= hw) { ++n; rem -= hw; }
-        int ig = (int)((float)rem * a.rcp_w);
-        int jg = rem - ig * a.Wg;
-        while (jg < 0) { --ig; jg += a.Wg; }
-        while (jg >= a.Wg) { ++ig; jg -= a.Wg; }
-        int hs = ig * a.in_stride + dh, ws = jg * a.in_stride + dw;
-        if ((unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws)
-          z = *(const uint4*)(a.src + (((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci + c);
-      }
-      ireg[i] = z;
-    }
-  };
-  auto write_lds = [&](int buf) {
-    unsigned char* ob = smem + buf * STAGE;
-    unsigned char* ib = ob + 64 * RBO;
-#pragma unroll
-    for (int i = 0; i < OCH; ++i) {
-      int q = tid + 256 * i;
-      int r = q / CO_CPR, ch = q - r * CO_CPR;
-      int c32 = (ch >> 1) ^ tr_swz(r, RBO / 32);
-      *(uint4*)(ob + r * RBO + c32 * 32 + (ch & 1) * 16) = oreg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < ICH; ++i) {
-      int q = tid + 256 * i;
-      int r = q / CI_CPR, ch = q - r * CI_CPR;
-      int c32 = (ch >> 1) ^ tr_swz(r, RBI / 32);
-      *(uint4*)(ib + r * RBI + c32 * 32 + (ch & 1) * 16) = ireg[i];
-    }
-  };
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (nk > 0) {
-    load_global(0);
-    write_lds(0);
-  }
-  __syncthreads();
-
-  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) load_global(ks + 1);
-    const unsigned char* ob = smem + buf * STAGE;
-    const unsigned char* ib = ob + 64 * RBO;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int r0 = kk * 32 + 8 * g + qq;  // pixel row this lane addresses (first half)
-      bf16x8 of[MT], xf[NT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        int c32 = wc * MT + m;  // 16-channel group == one 32-byte chunk
-        s16x4 lo = ds_read_tr16(ob + r0 * RBO + ((c32 ^ tr_swz(r0, RBO / 32)) * 32) + pp * 8);
-        s16x4 hi = ds_read_tr16(ob + (r0 + 4) * RBO + ((c32 ^ tr_swz(r0 + 4, RBO / 32)) * 32) + pp * 8);
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        of[m] = __builtin_bit_cast(bf16x8, v);
-      }
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        int c32 = wi * NT + n;
-        s16x4 lo = ds_read_tr16(ib + r0 * RBI + ((c32 ^ tr_swz(r0, RBI / 32)) * 32) + pp * 8);
-        s16x4 hi = ds_read_tr16(ib + (r0 + 4) * RBI + ((c32 ^ tr_swz(r0 + 4, RBI / 32)) * 32) + pp * 8);
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        xf[n] = __builtin_bit_cast(bf16x8, v);
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of[m], xf[n], acc[m][n], 0, 0, 0);
-    }
-    if (ks + 1 < nk) write_lds(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: [co][ci] fp32 tile through LDS, then 256-byte-contiguous atomics
-  const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int col = (wc * MT + m) * 16 + fq * 4 + r;
-        int cil = (wi * NT + n) * 16 + fr;
-        *(float*)(smem + col * EROW + cil * 4) = acc[m][n][r];
-      }
-  __syncthreads();
-  for (int q = tid; q < BCO * BCI; q += 256) {
-    int col = q / BCI, cil = q - col * BCI;
-    int co = co0 + col, ci = ci0 + cil;
-    if (co < a.Co && ci < a.Ci) {
-      float v = *(const float*)(smem + col * EROW + cil * 4);
-      atomicAdd(a.dw + ((long long)co * a.ntaps + tap) * a.Ci + ci, v);
-    }
-  }
-}
-
 
 // ds_read_b64_tr_b16 the compiler does not see (no automatic waits: pair with wait_lgkm_dyn + touch)
 template <int OFF>
@@ -2787,26 +1979,6 @@ unsigned long long make_tapcode(int ntaps, const int32_t* dh, const int32_t* dw,
 
 __device__ unsigned long long g_stamps[8];
 
-template <int WC, int WP, int MT, int NT>
-int launch_gemm(GemmArgs& a, hipStream_t st) {
-  constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
-  a.tilesC = a.Co_pad / BNC;
-  int tilesP = cdiv(a.M, BMP);
-  a.nblk = a.tilesC * tilesP;
-  size_t stage = (size_t)(BNC + BMP) * ROWB * 2;
-  size_t epi = (size_t)BMP * (BNC * (a.dst_f32 ? 4 : 2) + 16);
-  size_t lds = stage > epi ? stage : epi;
-  auto k = conv_gather_gemm_kernel<WC, WP, MT, NT>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-    attr = true;
-  }
-  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), lds, st, a);
-  return 0;
-}
-
-
 template <int WC, int WP, int MT, int NT, int NST>
 int launch_gemm2(GemmArgs& a, hipStream_t st) {
   constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
@@ -2826,24 +1998,6 @@ int launch_gemm2(GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
-
-template <int WC, int WP, int MT, int NT>
-int launch_gemm4(GemmArgs& a, hipStream_t st) {
-  constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
-  a.tilesC = a.Co_pad / BNC;
-  a.nblk = a.tilesC * cdiv(a.M, BMP);
-  size_t ring = (size_t)2 * BNC * ROWB + (size_t)2 * 137 * ROWB;     // must match RING / AUX in the kernel
-  size_t epi = (size_t)BMP * (BNC * 4 + 16);
-  size_t lds = (ring > epi ? ring : epi) + (size_t)BMP * 8;
-  auto k = conv_gemm4_kernel<WC, WP, MT, NT>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
-  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), lds, st, a);
-  return 0;
-}
 
 template <int WC, int WP, int MT, int NT, int NS>
 int launch_gemm6(GemmArgs& a, hipStream_t st) {
@@ -2888,25 +2042,6 @@ int launch_patch(GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
-template <int WC, int WP, int MT, int NT, int NST>
-int launch_gemm3(GemmArgs& a, hipStream_t st) {
-  constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
-  a.tilesC = a.Co_pad / BNC;
-  int tilesP = cdiv(a.M, BMP);
-  a.nblk = a.tilesC * tilesP;
-  size_t ring = (size_t)NST * (BNC + BMP) * 64;
-  size_t epi = (size_t)BMP * (BNC * 2 + 16);
-  ring = (ring > epi ? ring : epi) + (size_t)BMP * 8 + 1024;
-  auto k = conv_gemm3_kernel<WC, WP, MT, NT, NST>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
-  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(64 * WC * WP), ring, st, a);
-  return 0;
-}
-
 int launch_gemm2_stamped(GemmArgs& a, hipStream_t st) {
   constexpr int BNC = 128, BMP = 128, NST = 2;
   a.tilesC = a.Co_pad / BNC;
@@ -2928,16 +2063,10 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   size_t stage = (size_t)64 * (BCO + BCI) * 2 * 2;
   size_t epi = (size_t)BCO * (BCI + 4) * 4;
   size_t lds = stage > epi ? stage : epi;
-  static int variant = -1;
-  if (variant < 0) {
-    const char* e = getenv("MGD_WGRAD");
-    variant = e ? atoi(e) : 2;
-  }
-  auto k = variant == 1 ? conv_wgrad_kernel<WC, WI, MT, NT> : conv_wgrad2_kernel<WC, WI, MT, NT>;
+  auto k = conv_wgrad2_kernel<WC, WI, MT, NT>;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<WC, WI, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-    (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<WC, WI, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
     attr = true;
   }
   int nblk = a.tilesCo * a.tilesCi * a.ntaps * a.splits;
@@ -3036,14 +2165,10 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     variant = e ? atoi(e) : 3;
   }
   const int nk = d->K_pad / BK;
-  MGD_REQUIRE(!d->bn_y || variant == 3 || variant == 7 || variant == 9, "conv: the fused BN-backward reduction needs the default gemm variant (MGD_GEMM=3)");
-  // row-shift form: 3x3 in the standard tap order, stride 1, same-size maps, whole 64-channel chunks
-  bool std9 = d->ntaps == 9 && d->in_stride == 1 && d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 &&
-              d->Hs == d->Hg && d->Ws == d->Wg && d->Hd == d->Hg && d->Wd == d->Wg && d->Ci % BK == 0 &&
-              d->K_pad == 9 * d->Ci && (long long)d->N * d->Hs * d->Ws * d->Ci < (1ll << 30);
-  for (int t = 0; t < 9 && std9; ++t) std9 = d->dh[t] == t / 3 - 1 && d->dw[t] == t % 3 - 1;
-  static int rowshift = -1;
-  if (rowshift < 0) { const char* e = getenv("MGD_ROWSHIFT"); rowshift = e ? atoi(e) : 0; }   // opt-in: measured equal to v2 (the K-loop is not bound by LDS-DMA bytes)
+  MGD_REQUIRE(!d->bn_y || variant == 3 || variant == 9, "conv: the fused BN-backward reduction needs the default gemm variant (MGD_GEMM=3)");
+  // 32-bit byte offsets (SGPR base + VGPR offset) address the source tensor and the packed weights in every kernel below
+  MGD_REQUIRE((long long)d->N * d->Hs * d->Ws * d->Ci * 2 < (1ll << 32), "conv: source tensor exceeds 32-bit byte addressing (N*Hs*Ws*Ci*2 >= 4 GiB)");
+  MGD_REQUIRE((long long)d->Co_pad * d->K_pad * 2 < (1ll << 32), "conv: packed weights exceed 32-bit byte addressing");
   // patch form for the thin early layers: 3x3 in the standard tap order, 32 -> 64 channels, stride 1 or 2, bf16 output
   {
     static int patch = -1;
@@ -3076,25 +2201,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     MGD_CHECK_LAUNCH("conv_gather_gemm(producer/consumer)");
     return MGD_OK;
   }
-  if (variant == 3 && rowshift && std9) {
-    if (d->Co_pad % 128 == 0) launch_gemm4<2, 2, 4, 4>(a, st);
-    else if (d->Co_pad % 64 == 0) launch_gemm4<1, 4, 4, 2>(a, st);
-    else launch_gemm4<1, 4, 2, 2>(a, st);
-    MGD_CHECK_LAUNCH("conv_gather_gemm(row-shift)");
-    return MGD_OK;
-  }
-  if (variant == 1) {
-    if (d->Co_pad % 128 == 0) launch_gemm<2, 2, 4, 4>(a, st);
-    else if (d->Co_pad % 64 == 0) launch_gemm<1, 4, 4, 2>(a, st);
-    else launch_gemm<1, 4, 2, 2>(a, st);
-  } else if (variant == 7 && d->Co_pad % 128 == 0 && !d->dst_f32 && !d->bn_y) {
-    launch_gemm3<2, 2, 4, 4, 4>(a, st);      // experiment: 128x128 tile, BK = 32, 4-stage ring (2 K-steps in flight), 2 blocks/CU
-  } else if (variant == 6 && d->Co_pad % 128 == 0 && !d->dst_f32 && (long long)a.M * (d->Co_pad / 128) >= 256ll * 400) {
-    launch_gemm3<2, 2, 4, 8, 3>(a, st);      // 128 cout x 256 pixels, 128x64 wave tiles, BK = 32, 3-stage ring
-  } else if (variant == 5 && d->Co_pad % 64 == 0 && (long long)a.M * (d->Co_pad / (d->Co_pad % 128 == 0 ? 128 : 64)) >= 256ll * 200 && !d->dst_f32) {
-    // 8-wave, 256-pixel tile, 3-stage ring (1 block/CU): enough tiles to fill the chip
-    if (d->Co_pad % 128 == 0) launch_gemm2<2, 4, 4, 4, 3>(a, st); else launch_gemm2<1, 8, 4, 2, 3>(a, st);
-  } else {
+  {
     const bool deep = (variant == 2) ? nk >= 6 : (variant == 4);
     if (d->Co_pad % 128 == 0) {
       if (deep) launch_gemm2<2, 2, 4, 4, 4>(a, st);

@@ -117,6 +117,23 @@ def test_argument_validation_returns_einval_with_message():
     assert lib.mgd_comm_destroy(None) == 0          # destroying nothing is not an error
 
 
+def test_conv_rejects_tensors_beyond_32bit_offsets():
+    """The gather-GEMM kernels address the source tensor with 32-bit byte offsets from a scalar base: a source of 4 GiB
+    or more must be refused on the host (MGD_EINVAL), not silently wrapped (include/mgd_hip.h, mgd_conv_desc limits)."""
+    import ctypes as C
+    _lib = _build_if_needed()
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    fake = 0x10000                                   # never dereferenced: validation fails first
+    d.src, d.wpk, d.dst = fake, fake, fake
+    d.N, d.Hs, d.Ws, d.Ci = 400, 304, 304, 64        # 400*304*304*64*2 B = 4.7 GB
+    d.Hg, d.Wg, d.Hd, d.Wd, d.Co = 304, 304, 304, 304, 32
+    d.in_stride, d.out_stride, d.ntaps = 1, 1, 1
+    d.K_pad, d.Co_pad = 64, 32
+    assert lib.mgd_conv_gather_gemm(C.byref(d), None) == -1
+    assert b"32-bit byte addressing" in lib.mgd_last_error()
+
+
 def test_bucket_cut_points_follow_layer_boundaries():
     """Gradient buckets are contiguous, tile the flat buffer from the END (the order backward finalises layers in) and
     only ever start at a layer boundary."""
