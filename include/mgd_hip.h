@@ -254,6 +254,14 @@ typedef struct mgd_loss_cfg {
   int32_t use_focal_loss; /* 0 = BCE, 1 = sigmoid focal (losses/focal_loss.py:40-77) */
   float focal_alpha, focal_gamma;
   float grad_out_scale;   /* multiplies the gradient only (loss scaling); 1.0 normally */
+  /* loss_option 3 localisation (losses/iou_losses.py:36-237 via multigrid_loss.py:353-364): 0 = MSE (no flag set),
+   * 1 = GIoU, 2 = DIoU, 3 = CIoU.  iou_compat 0 = "tf_ref": the reference's arithmetic, including its
+   * [B,H,W] * [B,H,W,1] broadcast (defined for H == W and B == 1 or B == H only - MGD_EINVAL otherwise) on the raw
+   * offset / log-ratio tensors; 1 = "fixed": per-cell mask, boxes decoded to grid-cell units. */
+  int32_t iou_loss, iou_compat;
+  /* SoftmaxFocalLoss classification (losses/focal_loss.py:80-114 via multigrid_loss.py:815-828); softmax_compat as
+   * iou_compat (tf_ref additionally needs C == 1 or C == W: class_weights [1,1,1,C] multiplies along W). */
+  int32_t use_softmax_focal, softmax_compat;
 } mgd_loss_cfg;
 
 size_t mgd_loss_workspace_size(const mgd_loss_cfg* cfg);

@@ -83,6 +83,8 @@ class LossCfg(C.Structure):
         ("consensus_stop_gradient", C.c_int32),
         ("use_focal_loss", C.c_int32), ("focal_alpha", C.c_float), ("focal_gamma", C.c_float),
         ("grad_out_scale", C.c_float),
+        ("iou_loss", C.c_int32), ("iou_compat", C.c_int32),
+        ("use_softmax_focal", C.c_int32), ("softmax_compat", C.c_int32),
     ]
 
 

@@ -1,7 +1,19 @@
 // MultiGridLoss forward + backward on gfx950, one wavefront per grid cell.
 // Replaces MultiGridLoss.compute_loss and helpers (reference multigriddet/losses/multigrid_loss.py:233-443,
 // 445-492 IoU, 494-703 ignore mask, 729-757 MSE, 759-799 anchor BCE, 829-859 class BCE, 861-928
-// objectness, 930-1043 variance consensus; losses/focal_loss.py:40-77 sigmoid focal).
+// objectness, 930-1043 variance consensus; losses/focal_loss.py:40-77 sigmoid focal, :80-114 softmax focal;
+// losses/iou_losses.py:36-237 GIoU / DIoU / CIoU localisation, wired at multigrid_loss.py:353-364).
+//
+// GIoU/DIoU/CIoU and the softmax focal loss exist in two forms (cfg.iou_compat / cfg.softmax_compat):
+//  * 0 = "tf_ref": what the reference's TensorFlow code computes.  It multiplies a per-cell loss of shape [B,H,W] by the
+//    object mask of shape [B,H,W,1]; broadcasting aligns trailing dimensions, so the product is the 4-D tensor
+//    P[i,j,k,l] = loss[j,k,l] * mask[i,j,k] - defined only for H == W and (B == 1 or B == H) - and its sum is
+//    sum_{b,h,w} loss[b,h,w] * Wt[b,h] with Wt[b,h] = sum_i mask[i,b,h] (B == H) or sum_j mask[0,j,h] (B == 1).
+//    DIoU/CIoU subtract a keepdims [B,H,W,1] centre-distance term from the [B,H,W] IoU the same way, which adds
+//    W * sum_{positive cells} d2 / (c2 + eps).  The boxes are the raw tensors "as given" (grid offsets / log ratios).
+//    The softmax focal loss additionally multiplies by class_weights [1,1,1,C] along the W axis (C == 1 or C == W).
+//  * 1 = "fixed": the per-cell loss times the cell's own mask, boxes decoded to grid-cell units
+//    (xy = tanh(.15p)+sigmoid(.15p) against the target offset, wh = exp(t) * assigned anchor / stride).
 //
 // HBM-bound: algorithmic bytes = read y_pred + y_true (2 x B*cells*F*4) + write the gradient.
 // A cell's F = 5+A+C channels sit on the 64 lanes (coalesced 256-byte loads), the per-image list of
@@ -31,6 +43,8 @@ struct LossArgs {
   float4* gt;            // [sum_l B*g*g]
   float* assigned;       // [sum_l B*g*g]
   double* acc;           // [8]
+  float* wt;             // tf_ref broadcast weights Wt[l][b][h] (see the header comment); [sum_l B*gh]
+  long long wt_off[MAXL + 1];
   long long cell_off[MAXL + 1];
   float* components;
 };
@@ -80,7 +94,59 @@ __global__ void loss_prep_kernel(LossArgs a) {
   int slot = atomicAdd(a.gt_count + l * c.B + b, 1);
   a.gt[a.cell_off[l] + (long long)b * gh * gw + slot] = make_float4(gx, gy, w, h);
   atomicAdd(a.npos + l, 1);
+  if (a.wt) atomicAdd(a.wt + a.wt_off[l] + (c.B == 1 ? 0 : row) * gh + col, 1.0f);   // Wt[b'=row][h'=col] (B==H) / Wt[0][col] (B==1)
   if (t[0] >= 0.f && t[0] < 1.f && t[1] >= 0.f && t[1] < 1.f) atomicAdd(a.ncenter + l, 1);
+}
+
+
+// ---- forward-mode dual numbers for the IoU losses: lane j < 4 carries d/d(pred channel j)
+struct Dual { float v, d; };
+__device__ __forceinline__ Dual dc(float v) { return Dual{v, 0.f}; }
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return Dual{a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return Dual{a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return Dual{a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) {
+  float q = a.v / b.v;
+  return Dual{q, (a.d - q * b.d) / b.v};
+}
+// TF gradient conventions: maximum passes the gradient to x where x >= y, minimum where x <= y
+__device__ __forceinline__ Dual dmax(Dual a, Dual b) { return a.v >= b.v ? a : b; }
+__device__ __forceinline__ Dual dmin(Dual a, Dual b) { return a.v <= b.v ? a : b; }
+__device__ __forceinline__ Dual datan2(Dual y, Dual x) {
+  float den = x.v * x.v + y.v * y.v;
+  return Dual{atan2f(y.v, x.v), den > 0.f ? (x.v * y.d - y.v * x.d) / den : 0.f};
+}
+
+// One cell of GIoU / DIoU / CIoU (reference iou_losses.py:58-95, 121-160, 186-237) on centre-format boxes.
+// Returns the two parts of 1 - metric:  `cellpart` = the [B,H,W]-shaped part (1 - iou (+ enclosure / aspect terms)),
+// `distpart` = d2 / (c2 + eps), which the reference computes with keepdims (DIoU / CIoU only, else 0).
+__device__ __forceinline__ void iou_loss_cell(int kind, Dual tx, Dual ty, Dual tw, Dual th, Dual px, Dual py, Dual pw,
+                                              Dual ph, Dual& cellpart, Dual& distpart) {
+  const Dual half = dc(0.5f), zero = dc(0.f), eps = dc(KEPS), one = dc(1.f);
+  Dual tminx = tx - tw * half, tmaxx = tx + tw * half, tminy = ty - th * half, tmaxy = ty + th * half;
+  Dual pminx = px - pw * half, pmaxx = px + pw * half, pminy = py - ph * half, pmaxy = py + ph * half;
+  Dual iw = dmax(dmin(tmaxx, pmaxx) - dmax(tminx, pminx), zero);
+  Dual ih = dmax(dmin(tmaxy, pmaxy) - dmax(tminy, pminy), zero);
+  Dual inter = iw * ih;
+  Dual uni = tw * th + pw * ph - inter;
+  Dual iou = inter / (uni + eps);
+  Dual ew = dmax(dmax(tmaxx, pmaxx) - dmin(tminx, pminx), zero);
+  Dual eh = dmax(dmax(tmaxy, pmaxy) - dmin(tminy, pminy), zero);
+  distpart = zero;
+  if (kind == 1) {                       // GIoU
+    Dual earea = ew * eh;
+    cellpart = one - (iou - (earea - uni) / (earea + eps));
+    return;
+  }
+  Dual dx = tx - px, dy = ty - py;
+  distpart = (dx * dx + dy * dy) / (ew * ew + eh * eh + eps);
+  cellpart = one - iou;
+  if (kind == 3) {                       // CIoU: + alpha * v, alpha = v / (1 - iou + v + eps), differentiated through
+    Dual da = datan2(tw, th) - datan2(pw, ph);
+    Dual v = dc(4.0f / (3.14159265358979323846f * 3.14159265358979323846f)) * da * da;
+    Dual alpha = v / (one - iou + v + eps);
+    cellpart = cellpart + alpha * v;
+  }
 }
 
 // ---- K2: per-cell loss and gradient.  grid = (cells chunks, B, 1) per scale.
@@ -189,12 +255,80 @@ __global__ __launch_bounds__(256) void loss_cell_kernel(LossArgs a, CellsPerBloc
       wobj += (1.f - obj) * ignore * c.trainable_nms_weight *
               powf(fminf(fmaxf(max_iou, 0.f), 1.f) + KEPS, c.trainable_nms_power);
 
+    // IoU localisation (loss_option 3 + one of the flags): lanes 0-3 differentiate with respect to their own channel
+    const bool iou_mode = c.iou_loss != 0;
+    float iou_val = 0.f, iou_grad = 0.f;
+    const float t_x = __shfl(t0, 0, 64), t_y = __shfl(t0, 1, 64), t_w = __shfl(t0, 2, 64), t_h = __shfl(t0, 3, 64);
+    if (iou_mode && lane < 4) {
+      Dual px{pxr, lane == 0 ? 1.f : 0.f}, py{pyr, lane == 1 ? 1.f : 0.f};
+      Dual pw{pwr, lane == 2 ? 1.f : 0.f}, ph{phr, lane == 3 ? 1.f : 0.f};
+      Dual tx = dc(t_x), ty = dc(t_y), tw = dc(t_w), th = dc(t_h);
+      float wcell = obj, wdist = obj;
+      if (c.iou_compat == 0) {           // tf_ref: raw tensors, broadcast weights
+        wcell = a.wt[a.wt_off[l] + (c.B == 1 ? 0 : b) * gh + row];
+        wdist = obj * (float)gw;
+      } else {                           // fixed: decoded boxes in grid-cell units, assigned anchor
+        float aw = 0.f, ah = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXA; ++j)
+          if (j == kstar) { aw = c.anchors[l][j][0] / sx; ah = c.anchors[l][j][1] / sy; }
+        px = Dual{xy_act(pxr), px.d * xy_act_grad(pxr)};
+        py = Dual{xy_act(pyr), py.d * xy_act_grad(pyr)};
+        pw = Dual{ew * aw, pw.d * ew * aw};
+        ph = Dual{eh * ah, ph.d * eh * ah};
+        tw = dc(__expf(t_w) * aw);
+        th = dc(__expf(t_h) * ah);
+      }
+      if (wcell != 0.f || wdist != 0.f) {
+        Dual cp, dp;
+        iou_loss_cell(c.iou_loss, tx, ty, tw, th, px, py, pw, ph, cp, dp);
+        iou_val = wcell * cp.v + wdist * dp.v;
+        iou_grad = wcell * cp.d + wdist * dp.d;
+      }
+    }
+    // softmax focal classification (use_softmax_loss): one value per cell, reduced over the class channels
+    const bool smx = c.use_softmax_focal != 0;
+    float smx_w = 0.f, smx_lse = 0.f, smx_pt = 0.f, smx_ce = 0.f, smx_sy = 0.f;
+    if (smx) {
+      const bool c0 = ch0 >= 5 + A && ch0 < F, c1 = ch1 >= 5 + A && ch1 < F;
+      float m = wave_max(fmaxf(c0 ? p0 : -3.0e38f, c1 ? p1 : -3.0e38f));
+      float e0 = c0 ? __expf(p0 - m) : 0.f, e1 = c1 ? __expf(p1 - m) : 0.f;
+      float se = wave_sum(e0 + e1);
+      smx_lse = m + __logf(se);
+      smx_sy = wave_sum((c0 ? t0 : 0.f) + (c1 ? t1 : 0.f));
+      float syx = wave_sum((c0 ? t0 * p0 : 0.f) + (c1 ? t1 * p1 : 0.f));
+      smx_pt = wave_sum((c0 ? t0 * e0 : 0.f) + (c1 ? t1 * e1 : 0.f)) / se;
+      smx_ce = -syx + smx_sy * smx_lse;
+      if (c.softmax_compat == 0) {       // tf_ref: Wt[b,h] * class_weights[w] (C == W) or class_weights[0] (C == 1)
+        float cw = a.class_w ? a.class_w[C == 1 ? 0 : col] : 1.f;
+        smx_w = a.wt[a.wt_off[l] + (c.B == 1 ? 0 : b) * gh + row] * cw;
+      } else {                           // fixed: the cell's own mask, class weight of the true class
+        float cwt = wave_sum((c0 ? t0 * (a.class_w ? a.class_w[ch0 - 5 - A] : 1.f) : 0.f) +
+                             (c1 ? t1 * (a.class_w ? a.class_w[ch1 - 5 - A] : 1.f) : 0.f));
+        smx_w = obj * cwt;
+      }
+      if (lane == 0 && smx_w != 0.f) s_cls += smx_w * powf(fmaxf(1.f - smx_pt, 0.f), c.focal_gamma) * smx_ce;
+    }
+
     // per-channel loss / gradient
     float g0v = 0.f, g1v = 0.f;
     auto channel = [&](int ch, float pv, float tv, float& gout) {
       gout = 0.f;
       if (ch >= F) return;
-      if (ch < 2) {
+      if (ch < 4 && iou_mode) {
+        if (ch == 0) s_loc += iou_val;
+        gout = c.coord_scale * iou_grad * inv_nf;
+      } else if (ch >= 5 + A && smx) {
+        if (smx_w != 0.f) {
+          float om = fmaxf(1.f - smx_pt, 0.f);
+          float mod = powf(om, c.focal_gamma);
+          float sc = __expf(pv - smx_lse);                       // softmax_c
+          float dce = -tv + smx_sy * sc;
+          float dpt = sc * (tv - smx_pt);
+          float dmod = om > 0.f ? -c.focal_gamma * powf(om, c.focal_gamma - 1.f) * dpt : 0.f;
+          gout = c.class_scale * smx_w * (dmod * smx_ce + mod * dce) * inv_nf;
+        }
+      } else if (ch < 2) {
         float act = xy_act(pv);
         float d = act - tv;
         s_loc += obj * d * d;
@@ -359,8 +493,9 @@ __global__ void loss_finalize_kernel(LossArgs a) {
 }
 
 struct WsLayout {
-  size_t gt_count, npos, ncenter, acc, gt, assigned, gscratch, total;
+  size_t gt_count, npos, ncenter, acc, wt, gt, assigned, gscratch, total;
   long long cell_off[MAXL + 1];
+  long long wt_off[MAXL + 1];
 };
 
 WsLayout ws_layout(const mgd_loss_cfg* c) {
@@ -371,14 +506,19 @@ WsLayout ws_layout(const mgd_loss_cfg* c) {
     cells += (long long)c->B * c->grid_h[l] * c->grid_w[l];
   }
   w.cell_off[c->L] = cells;
+  long long nwt = 0;
+  for (int l = 0; l < c->L; ++l) {
+    w.wt_off[l] = nwt;
+    nwt += (long long)c->B * c->grid_h[l];
+  }
+  w.wt_off[c->L] = nwt;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
   w.acc = take(8 * sizeof(double));
   w.gt_count = take((size_t)c->L * c->B * 4);
   w.npos = take(MAXL * 4);
   w.ncenter = take(MAXL * 4);
-  size_t header = o;
-  (void)header;
+  w.wt = take((size_t)nwt * 4);          // zeroed with the header (everything before `gt`)
   w.gt = take((size_t)cells * 16);
   w.assigned = take((size_t)cells * 4);
   w.gscratch = take(c->use_consensus_loss ? (size_t)cells * (5 + c->A + c->C) * 4 : 0);
@@ -403,6 +543,23 @@ extern "C" int mgd_loss_fwd_bwd(const mgd_loss_cfg* cfg, const float* const* y_p
   MGD_REQUIRE(5 + cfg->A + cfg->C <= 128, "loss: 5+A+C=%d exceeds 128 channels", 5 + cfg->A + cfg->C);
   MGD_REQUIRE(cfg->loss_option >= 1 && cfg->loss_option <= 3, "loss: loss_option=%d", cfg->loss_option);
   MGD_REQUIRE(cfg->use_focal_loss == 0 || cfg->use_focal_loss == 1, "loss: use_focal_loss");
+  MGD_REQUIRE(cfg->iou_loss >= 0 && cfg->iou_loss <= 3 && (cfg->iou_loss == 0 || cfg->loss_option == 3),
+              "loss: iou_loss=%d needs loss_option 3", cfg->iou_loss);
+  MGD_REQUIRE((cfg->iou_compat | 1) == 1 && (cfg->softmax_compat | 1) == 1 && (cfg->use_softmax_focal | 1) == 1,
+              "loss: iou_compat / softmax_compat / use_softmax_focal must be 0 or 1");
+  const bool need_wt = (cfg->iou_loss != 0 && cfg->iou_compat == 0) || (cfg->use_softmax_focal && cfg->softmax_compat == 0);
+  if (need_wt) {
+    // the reference multiplies [B,H,W] by [B,H,W,1]: TensorFlow broadcasts that only for H == W and B in {1, H}
+    // (iou_losses.py:70-93, 140-158; multigrid_loss.py:815-828) and raises InvalidArgumentError otherwise
+    for (int l = 0; l < cfg->L; ++l) {
+      MGD_REQUIRE(cfg->grid_h[l] == cfg->grid_w[l] && (cfg->B == 1 || cfg->B == cfg->grid_h[l]),
+                  "loss: tf_ref broadcast of [B,H,W] * [B,H,W,1] is undefined for B=%d, grid %dx%d (scale %d); "
+                  "use compat='fixed'", cfg->B, cfg->grid_h[l], cfg->grid_w[l], l);
+      MGD_REQUIRE(!(cfg->use_softmax_focal && cfg->softmax_compat == 0) || cfg->C == 1 || cfg->C == cfg->grid_w[l],
+                  "loss: tf_ref softmax focal multiplies class_weights [1,1,1,C] along W: needs C == 1 or C == W "
+                  "(C=%d, W=%d)", cfg->C, cfg->grid_w[l]);
+    }
+  }
   WsLayout w = ws_layout(cfg);
   if (ws_bytes < w.total) return mgd_set_error(MGD_ENOSPC, "loss: workspace %zu < %zu", ws_bytes, w.total);
   LossArgs a;
@@ -414,6 +571,9 @@ extern "C" int mgd_loss_fwd_bwd(const mgd_loss_cfg* cfg, const float* const* y_p
   a.ncenter = (int*)(base + w.ncenter);
   a.gt = (float4*)(base + w.gt);
   a.assigned = (float*)(base + w.assigned);
+  a.wt = need_wt ? (float*)(base + w.wt) : nullptr;
+  for (int l = 0; l <= cfg->L; ++l) a.wt_off[l] = w.wt_off[l];
+  for (int l = cfg->L + 1; l <= MAXL; ++l) a.wt_off[l] = 0;
   a.class_w = class_weights;
   a.components = components;
   float* scratch = (float*)(base + w.gscratch);

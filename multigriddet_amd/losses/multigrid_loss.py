@@ -3,10 +3,15 @@
 Mirrors `MultiGridLoss(anchors, num_classes, input_shape, ...35 kwargs...)(y_true, y_pred) -> scalar`
 (reference multigriddet/losses/multigrid_loss.py:37-73, 190).  Same argument names, defaults and
 ValueErrors; tensors are torch CUDA tensors (numpy inputs are uploaded).  Differences, stated:
- * use_softmax_loss (SoftmaxFocalLoss, reference focal_loss.py:80-114) and the shape-broken
-   GIoU/DIoU/CIoU variants (unreachable from YAML in the reference) are not
-   implemented on the device and raise NotImplementedError; with loss_option=3 and no IoU flag the
-   reference falls back to MSE (multigrid_loss.py:365-368) and so does this.
+ * one extra keyword, `compat` ("tf_ref" default | "fixed"), for the two branches whose reference code is
+   shape-broken: GIoU/DIoU/CIoU localisation (loss_option=3 + use_giou_loss / use_diou_loss / use_ciou_loss,
+   losses/iou_losses.py:36-237) and use_softmax_loss (losses/focal_loss.py:80-114).  Both multiply a [B,H,W]
+   per-cell loss by the [B,H,W,1] object mask (iou_losses.py:70-93, multigrid_loss.py:815-828).  "tf_ref" computes
+   exactly what TensorFlow's broadcasting makes of that - defined for square grids and B == 1 or B == H, a
+   ValueError otherwise (TensorFlow raises InvalidArgumentError there; with three scales only B == 1 passes) - on
+   the raw offset / log-ratio tensors, as the reference feeds them.  "fixed" applies the mask per cell to boxes
+   decoded to grid-cell units.  With loss_option=3 and no IoU flag the reference falls back to MSE
+   (multigrid_loss.py:365-368) and so does this.
  * consensus_kernel_size must be 3 on the device path.
 """
 from typing import List, Optional, Sequence, Tuple
@@ -34,7 +39,7 @@ class MultiGridLoss:
                  consensus_iou_power: float = 1.5, consensus_min_iou: float = 1e-3,
                  consensus_coord_scale: float = 0.5, consensus_obj_scale: float = 0.5,
                  consensus_class_scale: float = 0.3, consensus_stop_gradient: bool = True,
-                 consensus_center_tolerance: float = 1e-4):
+                 consensus_center_tolerance: float = 1e-4, compat: str = "tf_ref"):
         self.anchors = [np.asarray(a, np.float32) for a in anchors]
         self.num_classes = num_classes
         self.input_shape = tuple(input_shape)
@@ -45,12 +50,12 @@ class MultiGridLoss:
             raise ValueError("consensus_kernel_size must be an odd positive integer")
         if use_consensus_loss and consensus_kernel_size != 3:
             raise NotImplementedError("device consensus loss supports consensus_kernel_size=3 only")
-        if use_softmax_loss:
-            raise NotImplementedError("use_softmax_loss is not implemented on the gfx950 path")
-        if loss_option == 3 and (use_giou_loss or use_diou_loss or use_ciou_loss):
-            raise NotImplementedError("GIoU/DIoU/CIoU localisation is shape-broken in the reference "
-                                      "(iou_losses.py:70-93) and not implemented here; loss_option=3 without the "
-                                      "flags is MSE, as in the reference")
+        if compat not in ("tf_ref", "fixed"):
+            raise ValueError(f"compat must be 'tf_ref' or 'fixed', got {compat!r}")
+        self.compat = compat
+        self._broadcast = compat == "tf_ref" and (use_softmax_loss or (
+            loss_option == 3 and (use_giou_loss or use_diou_loss or use_ciou_loss)))
+        self._softmax_ref = compat == "tf_ref" and use_softmax_loss
         self.class_weights = None if class_weights is None else np.asarray(class_weights, np.float32)
         if loss_normalization is None:
             loss_normalization = ["batch"]
@@ -66,7 +71,9 @@ class MultiGridLoss:
                        consensus_coord_scale=consensus_coord_scale, consensus_obj_scale=consensus_obj_scale,
                        consensus_class_scale=consensus_class_scale, consensus_stop_gradient=consensus_stop_gradient,
                        consensus_center_tolerance=consensus_center_tolerance, use_focal_loss=use_focal_loss,
-                       focal_alpha=focal_alpha, focal_gamma=focal_gamma)
+                       focal_alpha=focal_alpha, focal_gamma=focal_gamma, use_softmax_loss=use_softmax_loss,
+                       use_giou_loss=use_giou_loss, use_diou_loss=use_diou_loss, use_ciou_loss=use_ciou_loss,
+                       compat=compat)
         self.loss_option, self.loss_normalization = loss_option, loss_normalization
         self._runners = {}
 
@@ -79,6 +86,15 @@ class MultiGridLoss:
         B = y_pred[0].shape[0]
         grids = tuple((int(p.shape[1]), int(p.shape[2])) for p in y_pred)
         key = (B, grids)
+        if self._broadcast:
+            for gh, gw in grids:        # what TensorFlow's broadcast of [B,H,W] * [B,H,W,1] accepts
+                if gh != gw or B not in (1, gh):
+                    raise ValueError(f"Incompatible shapes: [{B},{gh},{gw}] vs. [{B},{gh},{gw},1] (the reference's "
+                                     f"IoU / softmax-focal branch broadcasts only for square grids and B == 1 or "
+                                     f"B == H; pass compat='fixed')")
+                if self._softmax_ref and self.num_classes not in (1, gw):
+                    raise ValueError(f"Incompatible shapes: [{B},{gh},{gw},{gw}] vs. [1,1,1,{self.num_classes}] "
+                                     f"(reference class_weights broadcast; pass compat='fixed')")
         if key not in self._runners:
             cfg = ops.make_loss_cfg(self.anchors, self.num_classes, self.input_shape, B, grids, **self.kw)
             self._runners[key] = ops.LossRunner(cfg, y_pred[0].device, class_weights=self.class_weights)

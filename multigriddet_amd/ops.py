@@ -448,6 +448,18 @@ def make_loss_cfg(anchors, num_classes, input_shape, batch, grid_shapes, **kw):
     cfg.consensus_stop_gradient = int(bool(kw.get("consensus_stop_gradient", True)))
     cfg.use_focal_loss = int(bool(kw.get("use_focal_loss", False)))
     cfg.grad_out_scale = float(kw.get("grad_out_scale", 1.0))
+    # loss_option 3: the first flag set wins, in the reference's order (multigrid_loss.py:353-364)
+    iou = 0
+    if cfg.loss_option == 3:
+        iou = 1 if kw.get("use_giou_loss") else 2 if kw.get("use_diou_loss") else 3 if kw.get("use_ciou_loss") else 0
+    cfg.iou_loss = iou
+    compat = kw.get("compat", "tf_ref")
+    if compat not in ("tf_ref", "fixed"):
+        raise ValueError(f"compat must be 'tf_ref' or 'fixed', got {compat!r}")
+    cfg.iou_compat = cfg.softmax_compat = 0 if compat == "tf_ref" else 1
+    cfg.use_softmax_focal = int(bool(kw.get("use_softmax_loss", False)))
+    if cfg.use_softmax_focal:
+        cfg.use_focal_loss = 0          # use_softmax_loss takes precedence (multigrid_loss.py:400-403)
     return cfg
 
 

@@ -14,8 +14,17 @@ reference gradient); every quirk of the TF code is kept:
   * anchor_scale applied twice (:349/:390 and :433); object_scale applied twice on positives
     (:908 and :432);
   * normalisation = product over `loss_normalization` entries, floored at 1 (:194-231).
+  * loss_option 3 with use_giou_loss / use_diou_loss / use_ciou_loss (losses/iou_losses.py:36-237 via
+    multigrid_loss.py:353-364) and use_softmax_loss (losses/focal_loss.py:80-114 via multigrid_loss.py:815-828):
+    compat="tf_ref" restates the code LITERALLY, including the product of a [B,H,W] loss with the [B,H,W,1] object mask -
+    torch broadcasts exactly as TensorFlow/numpy do (trailing dimensions aligned), so the 4-D result, and the
+    RuntimeError for shapes that do not broadcast (TF: InvalidArgumentError), come out of the same arithmetic; the boxes
+    are the raw tensors as given.  compat="fixed" is this build's repaired form (per-cell mask, boxes decoded to
+    grid-cell units with the assigned anchor) and has no reference counterpart.
+  * use_focal_loss (SigmoidFocalLoss, focal_loss.py:40-77 via multigrid_loss.py:800-813); use_softmax_loss takes
+    precedence when both are set (multigrid_loss.py:400-407).
 Keras semantics used: K.epsilon() = 1e-7; K.binary_crossentropy(from_logits=True) =
-max(x,0) - x*z + log1p(exp(-|x|)).
+max(x,0) - x*z + log1p(exp(-|x|)); K.categorical_crossentropy(from_logits=True) = -sum(y * log_softmax(x)).
 """
 import math
 
@@ -30,6 +39,62 @@ def bce_logits(z, x):
 
 def xy_act(p):
     return torch.tanh(0.15 * p) + torch.sigmoid(0.15 * p)
+
+
+def _box_terms(txy, twh, pxy, pwh):
+    """Shared head of GIoULoss/DIoULoss/CIoULoss.compute_loss (iou_losses.py:58-79, 121-141, 186-206)."""
+    tmin, tmax = txy - twh / 2.0, txy + twh / 2.0
+    pmin, pmax = pxy - pwh / 2.0, pxy + pwh / 2.0
+    iwh = torch.clamp(torch.minimum(tmax, pmax) - torch.maximum(tmin, pmin), min=0.0)
+    inter = iwh[..., 0] * iwh[..., 1]
+    union = twh[..., 0] * twh[..., 1] + pwh[..., 0] * pwh[..., 1] - inter
+    iou = inter / (union + EPS)
+    ewh = torch.clamp(torch.maximum(tmax, pmax) - torch.minimum(tmin, pmin), min=0.0)
+    return iou, union, ewh
+
+
+def giou_loss(txy, twh, pxy, pwh, mask):
+    """iou_losses.py:58-95.  mask is [B,H,W,1]; the [B,H,W] * [B,H,W,1] product broadcasts as in the reference."""
+    iou, union, ewh = _box_terms(txy, twh, pxy, pwh)
+    earea = ewh[..., 0] * ewh[..., 1]
+    giou = iou - (earea - union) / (earea + EPS)
+    return ((1.0 - giou) * mask).sum()
+
+
+def diou_loss(txy, twh, pxy, pwh, mask, keepdim=True):
+    """iou_losses.py:121-160 (centre distance and enclosing diagonal are keepdims tensors in the reference;
+    keepdim=False is the repaired per-cell form, mask [B,H,W])."""
+    iou, _, ewh = _box_terms(txy, twh, pxy, pwh)
+    cd = ((txy - pxy) ** 2).sum(-1, keepdim=keepdim)
+    ed = (ewh ** 2).sum(-1, keepdim=keepdim)
+    diou = iou - cd / (ed + EPS)
+    return ((1.0 - diou) * mask).sum()
+
+
+def ciou_loss(txy, twh, pxy, pwh, mask, keepdim=True):
+    """iou_losses.py:186-237 (alpha is NOT a stop-gradient in the reference)."""
+    iou, _, ewh = _box_terms(txy, twh, pxy, pwh)
+    cd = ((txy - pxy) ** 2).sum(-1, keepdim=keepdim)
+    ed = (ewh ** 2).sum(-1, keepdim=keepdim)
+    diou = iou - cd / (ed + EPS)
+    v = 4.0 * (torch.atan2(twh[..., 0], twh[..., 1]) - torch.atan2(pwh[..., 0], pwh[..., 1])) ** 2 / (math.pi * math.pi)
+    alpha = v / (1.0 - iou + v + EPS)
+    ciou = diou - alpha * v
+    return ((1.0 - ciou) * mask).sum()
+
+
+def sigmoid_focal(y, x, alpha, gamma):
+    """SigmoidFocalLoss.compute_loss, focal_loss.py:49-77."""
+    p = torch.sigmoid(x)
+    pt = y * p + (1 - y) * (1 - p)
+    return torch.pow(1.0 - pt, gamma) * (y * alpha + (1 - y) * (1 - alpha)) * bce_logits(y, x)
+
+
+def softmax_focal(y, x, gamma):
+    """SoftmaxFocalLoss.compute_loss, focal_loss.py:89-114 -> [B,H,W]."""
+    ce = -(y * torch.log_softmax(x, -1)).sum(-1)
+    pt = (y * torch.softmax(x, -1)).sum(-1)
+    return torch.pow(1.0 - pt, gamma) * ce
 
 
 def _patches(t, k=3):
@@ -53,7 +118,9 @@ class MultiGridLossOracle:
                  trainable_nms_power=2.0, use_consensus_loss=False, consensus_kernel_size=3,
                  consensus_iou_power=1.5, consensus_min_iou=1e-3, consensus_coord_scale=0.5,
                  consensus_obj_scale=0.5, consensus_class_scale=0.3, consensus_stop_gradient=True,
-                 consensus_center_tolerance=1e-4, dtype=torch.float32):
+                 consensus_center_tolerance=1e-4, use_focal_loss=False, use_softmax_loss=False, use_giou_loss=False,
+                 use_diou_loss=False, use_ciou_loss=False, focal_alpha=0.25, focal_gamma=2.0, compat="tf_ref",
+                 dtype=torch.float32):
         self.anchors = [torch.as_tensor(a, dtype=dtype) for a in anchors]
         self.C = num_classes
         self.input_shape = input_shape
@@ -79,6 +146,11 @@ class MultiGridLossOracle:
         self.ck, self.cpow, self.cmin = consensus_kernel_size, consensus_iou_power, consensus_min_iou
         self.ccs, self.cos, self.ccls = consensus_coord_scale, consensus_obj_scale, consensus_class_scale
         self.cstop, self.ctol = consensus_stop_gradient, consensus_center_tolerance
+        self.focal, self.softmax = use_focal_loss, use_softmax_loss
+        self.giou, self.diou, self.ciou = use_giou_loss, use_diou_loss, use_ciou_loss
+        self.falpha, self.fgamma = focal_alpha, focal_gamma
+        assert compat in ("tf_ref", "fixed")
+        self.compat = compat
 
     # multigrid_loss.py:194-231
     def _norm(self, B, gh, gw, obj):
@@ -143,8 +215,21 @@ class MultiGridLossOracle:
             ignore, assigned, maxiou = self._ignore(pxy, pwh, txy, twh, anc, obj, yt)
             nf = self._norm(B, gh, gw, obj)
             # localisation (:729-757); options 1, 2 and 3-without-flags are all MSE
-            loc = ((((txy - xy_act(pxy)) ** 2).sum(-1, keepdim=True) +
-                    ((twh - pwh) ** 2).sum(-1, keepdim=True)) * obj).sum() / nf
+            fn = None
+            if self.loss_option == 3:      # first flag set wins (:353-364)
+                fn = giou_loss if self.giou else diou_loss if self.diou else ciou_loss if self.ciou else None
+            if fn is None:
+                loc = ((((txy - xy_act(pxy)) ** 2).sum(-1, keepdim=True) +
+                        ((twh - pwh) ** 2).sum(-1, keepdim=True)) * obj).sum() / nf
+            elif self.compat == "tf_ref":
+                loc = fn(txy, twh, pxy, pwh, obj) / nf          # raw tensors, [B,H,W] * [B,H,W,1] broadcast
+            else:
+                # repaired form: per-cell mask, boxes in grid-cell units (wh = exp(t) * assigned anchor / stride)
+                aidx = torch.argmax(tanc, -1)
+                stride = torch.tensor([self.input_shape[1] / gw, self.input_shape[0] / gh], dtype=dt)
+                awh = anc[aidx] / stride
+                kw = {} if fn is giou_loss else {"keepdim": False}
+                loc = fn(txy, torch.exp(twh) * awh, xy_act(pxy), torch.exp(pwh) * awh, obj[..., 0], **kw) / nf
             tot["loc"] = tot["loc"] + loc
             # anchor (:759-799), pre-multiplied by anchor_scale (:349 / :390)
             al = (bce_logits(tanc, panc) * obj * (1.0 - ignore)).sum() / nf
@@ -160,8 +245,18 @@ class MultiGridLossOracle:
                 w = w + (1.0 - obj) * ignore * self.nms_w * torch.pow(torch.clamp(maxiou, 0.0, 1.0) + EPS, self.nms_pow)
             tot["obj"] = tot["obj"] + (bce_logits(tgt, pobj) * w).sum() / nf
             # classification (:829-859)
-            ts = tcls * (1.0 - self.label_smoothing) + self.label_smoothing / self.C if self.label_smoothing > 0 else tcls
-            tot["cls"] = tot["cls"] + (bce_logits(ts, pcls) * self.class_weights * obj).sum() / nf
+            if self.softmax:                 # :815-828 ([B,H,W] * [B,H,W,1] * [1,1,1,C] in the reference)
+                fl = softmax_focal(tcls, pcls, self.fgamma)
+                if self.compat == "tf_ref":
+                    cl = (fl * obj * self.class_weights.view(1, 1, 1, -1)).sum() / nf
+                else:
+                    cl = (fl * obj[..., 0] * (tcls * self.class_weights).sum(-1)).sum() / nf
+            elif self.focal:                 # :800-813
+                cl = (sigmoid_focal(tcls, pcls, self.falpha, self.fgamma) * obj * self.class_weights).sum() / nf
+            else:
+                ts = tcls * (1.0 - self.label_smoothing) + self.label_smoothing / self.C if self.label_smoothing > 0 else tcls
+                cl = (bce_logits(ts, pcls) * self.class_weights * obj).sum() / nf
+            tot["cls"] = tot["cls"] + cl
             if self.consensus:
                 cc, co, ccl = self._consensus(pxy, pwh, pobj, pcls, txy, obj, assigned)
                 tot["ccoord"], tot["cobj"], tot["ccls"] = tot["ccoord"] + cc, tot["cobj"] + co, tot["ccls"] + ccl
@@ -215,4 +310,5 @@ class MultiGridLossOracle:
         comp = self.components(y_true, yp)
         total = self.total(comp)
         total.backward()
-        return float(total), {k: float(v) for k, v in comp.items()}, [p.grad.detach().numpy() for p in yp]
+        return float(total.detach()), {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in comp.items()}, \
+            [p.grad.detach().numpy() for p in yp]

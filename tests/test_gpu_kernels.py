@@ -539,6 +539,162 @@ def test_loss_value_and_grad_vs_oracle(dev, kw, B, size):
         assert np.abs(gbd - gref).max() <= 8e-3 * scale
 
 
+# ---- L6 (GIoU / DIoU / CIoU localisation) and L8 (sigmoid / softmax focal classification)
+def _run_loss(dev, anchors, C, size, B, grids, yt, yp, cw, kw):
+    from multigriddet_amd import ops
+    cfg = ops.make_loss_cfg(anchors, C, (size, size), B, grids, **kw)
+    run = ops.LossRunner(cfg, dev, class_weights=cw)
+    ypd = [torch.from_numpy(a).to(dev) for a in yp]
+    gf = [torch.empty_like(a) for a in ypd]
+    c = run.run([torch.from_numpy(a).to(dev) for a in yt], ypd, grad_f32=gf).cpu().numpy()
+    torch.cuda.synchronize()
+    return c, [g.cpu().numpy() for g in gf]
+
+
+def _check_loss(c, gd, tot, comp, grads, tol=1e-4):
+    for i, n in enumerate(["loc", "obj", "anchor", "cls"]):
+        assert abs(c[i] - comp[n]) <= tol * max(1.0, abs(comp[n])), f"{n}: {c[i]} vs {comp[n]}"
+    assert abs(c[7] - tot) <= tol * max(1.0, abs(tot)), f"total {c[7]} vs {tot}"
+    for l in range(len(grads)):
+        scale = max(1.0, np.abs(grads[l]).max())
+        assert np.abs(gd[l] - grads[l]).max() <= tol * scale, f"grad layer {l}: {np.abs(gd[l] - grads[l]).max()} / {scale}"
+        # the localisation channels on their own scale (they can be much smaller than the objectness gradient)
+        gl, rl = gd[l][..., :4], grads[l][..., :4]
+        assert np.abs(gl - rl).max() <= 3e-4 * np.abs(rl).max() + 1e-7, f"loc grad layer {l}: {np.abs(gl - rl).max()} / {np.abs(rl).max()}"
+
+
+def _positive_wh(yp):
+    """Predicted wh strictly positive (raw tensors are the 'boxes' in tf_ref mode): keeps areas away from the 0/0 regime
+    in which float32 and float64 legitimately disagree."""
+    for a in yp:
+        a[..., 2:4] = np.abs(a[..., 2:4]) + 0.3
+    return yp
+
+
+@pytest.mark.parametrize("flag", ["use_giou_loss", "use_diou_loss", "use_ciou_loss"])
+def test_iou_losses_tf_ref_three_scales_batch1(dev, flag):
+    """compat='tf_ref' at (1, 608): the only batch size for which the reference's three-scale IoU branch is defined."""
+    from oracle.loss import MultiGridLossOracle
+    yt, yp, grids = _loss_inputs(1, 608, seed=4)
+    yp = _positive_wh(yp)
+    kw = dict(loss_option=3, coord_scale=2.0, **{flag: True})
+    tot, comp, grads = MultiGridLossOracle(coco_anchors(), 80, (608, 608), dtype=torch.float64, **kw).value_and_grad(yt, yp)
+    c, gd = _run_loss(dev, coco_anchors(), 80, 608, 1, grids, yt, yp, None, kw)
+    assert comp["loc"] > 0
+    _check_loss(c, gd, tot, comp, grads)
+
+
+@pytest.mark.parametrize("flag", ["use_giou_loss", "use_diou_loss", "use_ciou_loss"])
+def test_iou_losses_tf_ref_batch_equals_grid(dev, flag):
+    """compat='tf_ref' with B == H == 19 on the 19x19 scale of a 608 input (one-scale loss: with three scales TensorFlow
+    rejects every B > 1, see test_iou_losses_tf_ref_rejects_undefined_broadcast)."""
+    from oracle.loss import MultiGridLossOracle
+    yt, yp, grids = _loss_inputs(19, 608, seed=5)
+    yt, yp, grids = yt[:1], _positive_wh(yp[:1]), grids[:1]
+    anchors = coco_anchors()[:1]
+    kw = dict(loss_option=3, **{flag: True})
+    tot, comp, grads = MultiGridLossOracle(anchors, 80, (608, 608), dtype=torch.float64, **kw).value_and_grad(yt, yp)
+    c, gd = _run_loss(dev, anchors, 80, 608, 19, grids, yt, yp, None, kw)
+    _check_loss(c, gd, tot, comp, grads)
+
+
+def test_iou_losses_tf_ref_rejects_undefined_broadcast(dev):
+    from multigriddet_amd.losses import MultiGridLoss
+    from multigriddet_amd import _lib
+    yt, yp, grids = _loss_inputs(16, 608, seed=1)
+    loss = MultiGridLoss(coco_anchors(), 80, (608, 608), loss_option=3, use_giou_loss=True)
+    with pytest.raises(ValueError, match="Incompatible shapes"):
+        loss(yt, yp)
+    with pytest.raises(_lib.MgdError, match="broadcast"):       # the C-ABI refuses it too
+        _run_loss(dev, coco_anchors(), 80, 608, 16, grids, yt, yp, None, dict(loss_option=3, use_giou_loss=True))
+    # without a flag loss_option 3 is MSE, at any batch size (reference multigrid_loss.py:365-368)
+    v = MultiGridLoss(coco_anchors(), 80, (608, 608), loss_option=3)(yt, yp)
+    v2 = MultiGridLoss(coco_anchors(), 80, (608, 608), loss_option=1)(yt, yp)
+    assert float(v) == float(v2)
+
+
+@pytest.mark.parametrize("flag", ["use_giou_loss", "use_diou_loss", "use_ciou_loss"])
+def test_iou_losses_fixed_batch16(dev, flag):
+    """compat='fixed' at (16, 608): per-cell mask, boxes decoded to grid-cell units with the assigned anchor."""
+    from oracle.loss import MultiGridLossOracle
+    yt, yp, grids = _loss_inputs(16, 608, seed=6)
+    kw = dict(loss_option=3, compat="fixed", coord_scale=3.0, **{flag: True})
+    tot, comp, grads = MultiGridLossOracle(coco_anchors(), 80, (608, 608), dtype=torch.float64, **kw).value_and_grad(yt, yp)
+    c, gd = _run_loss(dev, coco_anchors(), 80, 608, 16, grids, yt, yp, None, kw)
+    assert comp["loc"] > 0
+    _check_loss(c, gd, tot, comp, grads)
+
+
+@pytest.mark.parametrize("B,size", [(3, 416), (16, 608)])
+def test_sigmoid_focal_vs_oracle(dev, B, size):
+    from oracle.loss import MultiGridLossOracle
+    yt, yp, grids = _loss_inputs(B, size, seed=7)
+    cw = np.linspace(0.5, 2.0, 80).astype(np.float32)
+    kw = dict(loss_option=2, use_focal_loss=True, focal_alpha=0.3, focal_gamma=1.5, class_scale=2.0)
+    tot, comp, grads = MultiGridLossOracle(coco_anchors(), 80, (size, size), class_weights=cw, dtype=torch.float64,
+                                           **kw).value_and_grad(yt, yp)
+    c, gd = _run_loss(dev, coco_anchors(), 80, size, B, grids, yt, yp, cw, kw)
+    assert comp["cls"] > 0
+    _check_loss(c, gd, tot, comp, grads)
+
+
+def test_softmax_focal_fixed_batch16(dev):
+    from oracle.loss import MultiGridLossOracle
+    yt, yp, grids = _loss_inputs(16, 608, seed=8)
+    cw = np.linspace(0.5, 2.0, 80).astype(np.float32)
+    kw = dict(loss_option=2, use_softmax_loss=True, use_focal_loss=True, compat="fixed", focal_gamma=2.0, class_scale=1.5)
+    tot, comp, grads = MultiGridLossOracle(coco_anchors(), 80, (608, 608), class_weights=cw, dtype=torch.float64,
+                                           **kw).value_and_grad(yt, yp)
+    c, gd = _run_loss(dev, coco_anchors(), 80, 608, 16, grids, yt, yp, cw, kw)
+    assert comp["cls"] > 0
+    _check_loss(c, gd, tot, comp, grads)
+
+
+@pytest.mark.parametrize("B", [1, 19])
+def test_softmax_focal_tf_ref_classes_equal_grid_width(dev, B):
+    """compat='tf_ref': [B,H,W] * [B,H,W,1] * class_weights[1,1,1,C] is defined for C == W (and B in {1, H}) - here the
+    19x19 scale with 19 classes; the class weight then multiplies along the grid's W axis, as TensorFlow computes it."""
+    from oracle import targets as ot
+    from oracle.loss import MultiGridLossOracle
+    C, size = 19, 608
+    anchors = coco_anchors()[:1]
+    rng = np.random.default_rng(9 + B)
+    tb = np.zeros((B, 6, 5), np.float32)
+    for b in range(B):
+        for t in range(3):
+            w, h = rng.uniform(100, 400, 2)
+            cx, cy = rng.uniform(w / 2, size - w / 2), rng.uniform(h / 2, size - h / 2)
+            tb[b, t] = [cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, rng.integers(0, C)]
+    yt = ot.tf_preprocess_true_boxes(tb, (size, size), anchors, C, grid_shapes=[(19, 19)])
+    yp = [rng.standard_normal((B, 19, 19, 5 + 3 + C)).astype(np.float32)]
+    cw = np.linspace(0.5, 2.0, C).astype(np.float32)
+    kw = dict(loss_option=2, use_softmax_loss=True, focal_gamma=2.0)
+    tot, comp, grads = MultiGridLossOracle(anchors, C, (size, size), class_weights=cw, dtype=torch.float64,
+                                           **kw).value_and_grad(yt, yp)
+    c, gd = _run_loss(dev, anchors, C, size, B, [(19, 19)], yt, yp, cw, kw)
+    assert comp["cls"] > 0
+    _check_loss(c, gd, tot, comp, grads)
+
+
+def test_softmax_focal_tf_ref_three_scales_single_class(dev):
+    """The reference's three-scale softmax branch runs only for one class and B == 1: softmax of one logit is 1, the
+    cross entropy 0 - the classification term and its gradient vanish identically."""
+    from oracle import targets as ot
+    from oracle.loss import MultiGridLossOracle
+    size, B, C = 416, 1, 1
+    tb = np.array([[[100, 120, 260, 300, 0], [20, 30, 80, 70, 0]]], np.float32)
+    grids = [(13, 13), (26, 26), (52, 52)]
+    yt = ot.tf_preprocess_true_boxes(tb, (size, size), coco_anchors(), C)
+    yp = [np.random.default_rng(l).standard_normal((B, g[0], g[1], 9)).astype(np.float32) for l, g in enumerate(grids)]
+    kw = dict(loss_option=2, use_softmax_loss=True)
+    tot, comp, grads = MultiGridLossOracle(coco_anchors(), C, (size, size), dtype=torch.float64, **kw).value_and_grad(yt, yp)
+    c, gd = _run_loss(dev, coco_anchors(), C, size, B, grids, yt, yp, None, kw)
+    assert comp["cls"] == 0.0 and c[3] == 0.0
+    _check_loss(c, gd, tot, comp, grads)
+    for g in gd:
+        assert np.abs(g[..., 8:]).max() == 0.0
+
+
 def test_loss_empty_targets(dev):
     from multigriddet_amd import ops
     from oracle.loss import MultiGridLossOracle
