@@ -284,6 +284,7 @@ typedef struct mgd_decode_cfg {
   int32_t use_softmax, rescore;
   float confidence;
   int32_t cap; /* candidate capacity per image (>= total cells to be safe) */
+  int32_t tag_scale; /* 1: cand_cls = class | scale << 16, for mgd_nms(method | MGD_NMS_PER_SCALE) */
 } mgd_decode_cfg;
 
 size_t mgd_decode_workspace_size(const mgd_decode_cfg* cfg);
@@ -296,6 +297,11 @@ int mgd_decode(const mgd_decode_cfg* cfg, const float* const* y_pred_host, const
  * original candidate order with their decayed scores, or the top max_boxes by decayed score if more survive).
  * out_boxes i32 [B][max_boxes][4] (xyxy, clipped, floor(v+0.5)) or f32 xywh if !return_xyxy;
  * out_count[b] = number of detections.  Workspace: mgd_nms_workspace_size(B, cap) bytes. */
+/* method | MGD_NMS_PER_SCALE (greedy methods): "per-scale NMS" of the north-star - a box only suppresses boxes decoded
+ * from its own scale (the scale id is read from cand_cls >> 16, see mgd_decode_cfg.tag_scale, and stripped from the
+ * output); ranking and the top-max_boxes cut stay global, all in the same single launch.  NOT the reference's
+ * semantics (multigrid_decode.py:98 concatenates the scales before NMS): an option, off by default. */
+#define MGD_NMS_PER_SCALE 0x100
 size_t mgd_nms_workspace_size(int B, int cap);
 int mgd_nms(const float* cand_boxes, const float* cand_scores, const int32_t* cand_cls,
             const int32_t* cand_count, int B, int cap, int method, float threshold, int max_boxes,
@@ -354,6 +360,20 @@ int mgd_comm_unique_id(void* id128);
 int mgd_comm_init(void** comm, int rank, int world, const void* id128);
 int mgd_comm_allreduce_bucket(void* comm, float* grads, int64_t count, void* stream);
 int mgd_comm_destroy(void* comm);
+
+/* ----------------------------------------------------------------------------------------------
+ * Inference-side letterbox on the device (multigriddet/utils/preprocessing.py:12-90: PIL Image.resize(BICUBIC) +
+ * centred paste on a (128,128,128) canvas + /255).  src: uint8 [H][W][3] device frame; dst: f32 [Hd][Wd][3] (one image
+ * slot of the NHWC model input).  (nw, nh) = int(W*scale), int(H*scale), scale = min(Wd/W, Hd/H); (dx, dy) = centred
+ * offset.  kx/bx, ky/by: PIL's fixed-point resampling tables for the horizontal (W -> nw) and vertical (H -> nh) pass:
+ * k[out][ks] int32 coefficients (22 fractional bits), b[out][2] = (first source index, count); device pointers, built
+ * by the host (multigriddet_amd/utils/preprocessing.py: resample_tables).  Result equals PIL's bit for bit.
+ * Workspace: mgd_letterbox_workspace_size(H, nw) bytes (the 8-bit intermediate of the horizontal pass).
+ * ---------------------------------------------------------------------------------------------- */
+size_t mgd_letterbox_workspace_size(int H, int nw);
+int mgd_letterbox_u8(const uint8_t* src, int H, int W, float* dst, int Hd, int Wd, int nh, int nw, int dy, int dx,
+                     const int32_t* kx, const int32_t* bx, int ksx, const int32_t* ky, const int32_t* by, int ksy,
+                     float fill, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

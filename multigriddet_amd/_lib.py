@@ -95,7 +95,7 @@ class DecodeCfg(C.Structure):
         ("grid_h", C.c_int32 * 4), ("grid_w", C.c_int32 * 4),
         ("anchors", (C.c_float * 2) * 8 * 4),
         ("use_softmax", C.c_int32), ("rescore", C.c_int32),
-        ("confidence", C.c_float), ("cap", C.c_int32),
+        ("confidence", C.c_float), ("cap", C.c_int32), ("tag_scale", C.c_int32),
     ]
 
 
@@ -108,6 +108,7 @@ EXPORTS = [
     "mgd_loss_workspace_size", "mgd_loss_fwd_bwd", "mgd_decode_workspace_size", "mgd_decode",
     "mgd_nms_workspace_size", "mgd_nms", "mgd_wbf_workspace_size", "mgd_wbf", "mgd_iou_matrix", "mgd_eval_match", "mgd_mosaic", "mgd_gridmask", "mgd_mixup",
     "mgd_comm_unique_id", "mgd_comm_init", "mgd_comm_allreduce_bucket", "mgd_comm_destroy",
+    "mgd_letterbox_workspace_size", "mgd_letterbox_u8",
 ]
 
 
@@ -123,7 +124,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.mgd_last_error.restype = C.c_char_p
     for name in ("mgd_build_targets_workspace_size", "mgd_loss_workspace_size", "mgd_decode_workspace_size",
-                 "mgd_nms_workspace_size", "mgd_wbf_workspace_size"):
+                 "mgd_nms_workspace_size", "mgd_wbf_workspace_size", "mgd_letterbox_workspace_size"):
         getattr(lib, name).restype = C.c_size_t
     _lib = lib
     return lib

@@ -39,6 +39,10 @@ def build_model_from_config(config, for_training=False, anchors: List = None, we
     arch, num_classes, input_shape = preset["architecture"], preset["num_classes"], tuple(preset["input_shape"])
     if arch not in ("multigriddet_darknet", "multigriddet_resnet"):
         raise ValueError(f"Unknown architecture: {arch}")
+    if arch == "multigriddet_resnet":
+        # the reference dispatches this to build_multigriddet_resnet(_train) (config/model_builder.py:248-262);
+        # outside the Darknet53 hot path built here - fail loudly rather than silently build Darknet53
+        raise NotImplementedError("architecture 'multigriddet_resnet' is not built on the gfx950 path; use multigriddet_darknet")
     if not for_training:
         return build_multigriddet_darknet(input_shape=input_shape, num_classes=num_classes,
                                           num_anchors_per_head=[3, 3, 3],

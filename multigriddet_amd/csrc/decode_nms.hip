@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecArgs a) {
   long long o = (long long)b * T + k;
   *(float4*)(a.dboxes + o * 4) = make_float4(bx, by, bw, bh);
   a.dscores[o] = score;
-  a.dcls[o] = ci;
+  a.dcls[o] = c.tag_scale ? (ci | (l << 16)) : ci;     // per-scale NMS: the scale rides in the upper half of the class id
 }
 
 // ordered compaction: one block per image
@@ -150,7 +150,7 @@ struct NmsArgs {
   const float* scores;  // [B][cap]
   const int* cls;       // [B][cap]
   const int* count;     // [B]
-  int B, cap, method, max_boxes, return_xyxy, npow2;
+  int B, cap, method, max_boxes, return_xyxy, npow2, per_scale;
   float thr;
   const float* image_hw;
   void* out_boxes;
@@ -215,9 +215,11 @@ __global__ __launch_bounds__(1024) void nms_kernel(NmsArgs a) {
   bitonic_desc(keys, np2, tid);
   // gather boxes in sorted order (global scratch, L2 resident)
   float* sb = a.sorted + (long long)b * a.cap * 4;
+  int* sseg = (int*)(a.sorted + (long long)a.B * a.cap * 4) + (long long)b * a.cap;   // per-scale mode only
   for (int i = tid; i < n; i += 1024) {
     int src = (int)(keys[i] & 0xffffffffu);
     *(float4*)(sb + (long long)i * 4) = *(const float4*)(bx + (long long)src * 4);
+    if (a.per_scale) sseg[i] = a.cls[(long long)b * a.cap + src] >> 16;
   }
   const int nw = (n + 31) >> 5;
   for (int i = tid; i < nw; i += 1024) {
@@ -239,8 +241,10 @@ __global__ __launch_bounds__(1024) void nms_kernel(NmsArgs a) {
     if (tid == 0) kept_idx[K] = i;
     ++K;
     float4 cur = *(const float4*)(sb + (long long)i * 4);
+    const int cseg = a.per_scale ? sseg[i] : 0;
     for (int j = i + 1 + tid; j < n; j += 1024) {
       if (alive[j >> 5] & (1u << (j & 31))) {
+        if (a.per_scale && sseg[j] != cseg) continue;      // a box only suppresses boxes of its own scale
         float4 o = *(const float4*)(sb + (long long)j * 4);
         if (!(pair_metric(cur, o, a.method) < a.thr)) atomicAnd(&alive[j >> 5], ~(1u << (j & 31)));
       }
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(NmsArgs a) {
       *(float4*)((float*)a.out_boxes + o * 4) = B4;
     }
     a.out_scores[o] = sc[src];
-    a.out_cls[o] = a.cls[(long long)b * a.cap + src];
+    a.out_cls[o] = a.per_scale ? (a.cls[(long long)b * a.cap + src] & 0xffff) : a.cls[(long long)b * a.cap + src];
   }
 }
 
@@ -560,7 +564,10 @@ extern "C" int mgd_nms(const float* cand_boxes, const float* cand_scores, const 
   MGD_REQUIRE(cand_boxes && cand_scores && cand_cls && cand_count && image_hw && out_boxes && out_scores && out_cls &&
                   out_count && ws,
               "nms: null pointer");
+  const int per_scale = (method & MGD_NMS_PER_SCALE) ? 1 : 0;
+  method &= ~MGD_NMS_PER_SCALE;
   MGD_REQUIRE(method >= 0 && method <= 2, "nms: method %d unknown (0=iou, 1=diou, 2=soft)", method);
+  MGD_REQUIRE(!(per_scale && method == 2), "nms: per-scale suppression is for the greedy methods (iou / diou)");
   MGD_REQUIRE(max_boxes >= 1 && max_boxes <= 1024, "nms: max_boxes=%d must be in [1,1024]", max_boxes);
   MGD_REQUIRE(cap >= 1 && cap <= 16384, "nms: cap=%d must be in [1,16384]", cap);
   if (ws_bytes < (size_t)B * cap * 24) return mgd_set_error(MGD_ENOSPC, "nms: workspace too small");
@@ -568,7 +575,7 @@ extern "C" int mgd_nms(const float* cand_boxes, const float* cand_scores, const 
   a.boxes = cand_boxes; a.scores = cand_scores; a.cls = cand_cls; a.count = cand_count;
   a.B = B; a.cap = cap; a.method = method; a.max_boxes = max_boxes; a.return_xyxy = return_xyxy; a.thr = threshold;
   a.image_hw = image_hw; a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_cls = out_cls;
-  a.out_count = out_count; a.sorted = (float*)ws;
+  a.out_count = out_count; a.sorted = (float*)ws; a.per_scale = per_scale;
   int np2 = 1;
   while (np2 < cap) np2 <<= 1;
   a.npow2 = np2;

@@ -6,9 +6,13 @@
    iou_thresh=0.2)  (reference :3393; asserts class id < num_classes like the reference :3409)
  * MultiGridDataGenerator(annotation_lines, batch_size, input_shape, anchors, num_classes, ...)
    (reference :1403-1419): len(), [i] -> ((images, y0, y1, y2), zeros(B)), on_epoch_end().
-   Host side it only parses annotation lines and letterboxes images (PIL); Mosaic / MixUp / GridMask
-   and the target encoding run on the device.  JPEG decode and the PIL/imgaug colour pipeline of the
-   reference are host I/O outside the accelerated path and are not reproduced.
+   Host side (a thread pool of `num_workers`, like the reference's Sequence path :1640-1700): parse the annotation
+   line, decode, letterbox (zero pad, :167-209), the per-image augmentation chain of the tf.data path (:1918-1943,
+   restated in data/host_aug.py) and the Sequence path's multi-scale jitter (`rescale_interval`, :1627-1633: every
+   n-th batch is letterboxed to a random shape of get_multiscale_list() and resized back to the model input - the model
+   input itself never changes size in the reference).  Mosaic / MixUp / GridMask and the target encoding run on the
+   device.  `native_multiscale=True` is an extension: the sampled shape becomes the batch's resolution (the engine keeps
+   one arena per resolution, BASELINE config 3).
 """
 import os
 from typing import List, Optional, Sequence, Tuple
@@ -88,7 +92,10 @@ class MultiGridDataGenerator:
                  enhance_augment: Optional[str] = None, rescale_interval: int = -1,
                  multi_anchor_assign: bool = False, shuffle: bool = True, prefetch_factor: int = 2,
                  num_workers: int = 8, mosaic_prob: float = 0.3, mixup_prob: float = 0.1,
-                 max_boxes_per_image: int = 100, seed: int = 0, gridmask_prob: float = 0.1, **kwargs):
+                 max_boxes_per_image: int = 100, seed: int = 0, gridmask_prob: float = 0.1,
+                 host_augment: Optional[bool] = None, native_multiscale: bool = False, **kwargs):
+        if enhance_augment not in (None, "mosaic"):
+            raise ValueError(f"enhance_augment={enhance_augment!r}: only None or 'mosaic' exist (reference generators.py:1505)")
         self.annotation_lines = list(annotation_lines)
         self.batch_size = batch_size
         self.input_shape = tuple(input_shape)
@@ -102,8 +109,20 @@ class MultiGridDataGenerator:
         self.num_layers = len(anchors)
         self.grid_shapes = [(self.input_shape[0] // s, self.input_shape[1] // s) for s in (32, 16, 8, 4, 2)][:self.num_layers]
         self.rng = np.random.default_rng(seed)
+        self.host_augment = augment if host_augment is None else bool(host_augment)
+        self.native_multiscale = bool(native_multiscale)
+        self.num_workers = max(1, int(num_workers))
+        self.rescale_step = 0
+        self.input_shape_list = get_multiscale_list()
+        self._executor = None
         if shuffle:
             self.rng.shuffle(self.indexes)
+
+    def _pool(self):
+        if self._executor is None and self.num_workers > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._executor = ThreadPoolExecutor(max_workers=self.num_workers)
+        return self._executor
 
     def _calculate_expansion_factor(self) -> int:
         """reference generators.py:1492-1517: 8x (Mosaic+MixUp), 4x, 2x, 1x."""
@@ -118,23 +137,51 @@ class MultiGridDataGenerator:
         if self.shuffle:
             self.rng.shuffle(self.indexes)
 
-    def _load(self, line):
+    def _load(self, line, target_shape=None, out_shape=None, seed=None):
+        """One image: decode -> letterbox to target_shape (-> bilinear resize to out_shape when they differ, the
+        reference's cv2.resize at :1655) -> per-image augmentation chain.  Thread-safe: its own Generator."""
         from PIL import Image
+        target_shape = tuple(target_shape or self.input_shape)
+        out_shape = tuple(out_shape or target_shape)
         path, boxes = parse_annotation_line(line)
         img = Image.open(path).convert("RGB")
-        return letterbox(img, boxes, self.input_shape, fill=0)
+        im, bx = letterbox(img, boxes, target_shape, fill=0)
+        if out_shape != target_shape:
+            oh, ow = out_shape
+            im = np.asarray(Image.fromarray(im.astype(np.uint8)).resize((ow, oh), Image.BILINEAR), np.float32)
+            if len(bx):
+                bx[:, [0, 2]] *= ow / target_shape[1]
+                bx[:, [1, 3]] *= oh / target_shape[0]
+        if self.host_augment:
+            from . import host_aug
+            im, bx = host_aug.augment_image(np.random.default_rng(seed), im, bx, out_shape)
+        return im, bx
+
+    def next_shape(self):
+        """Sequence-path multi-scale (reference :1627-1633): every rescale_interval-th batch draws a shape."""
+        if self.rescale_interval > 0:
+            self.rescale_step = (self.rescale_step + 1) % self.rescale_interval
+            if self.rescale_step == 0:
+                return self.input_shape_list[int(self.rng.integers(0, len(self.input_shape_list)))]
+        return self.input_shape
 
     def load_batch(self, i):
-        """Host part: returns (images uint8-range fp32 [B,H,W,3], boxes [B, capacity, 5])."""
+        """Host part: returns (images uint8-range fp32 [B,H,W,3], boxes [B, capacity, 5]).  The last batch of an epoch is
+        filled up from the start of the (shuffled) index list, so every batch has batch_size images."""
         idx = self.indexes[i * self.batch_size:(i + 1) * self.batch_size]
         if len(idx) < self.batch_size:
-            idx = np.concatenate([idx, self.indexes[:self.batch_size - len(idx)]])
+            idx = np.concatenate([idx, np.resize(self.indexes, self.batch_size - len(idx))])
         cap = self.max_boxes_per_image * (self._calculate_expansion_factor() if self.augment else 1)
-        H, W = self.input_shape
+        target = tuple(self.next_shape())
+        out = target if self.native_multiscale else self.input_shape
+        H, W = out
         images = np.zeros((self.batch_size, H, W, 3), np.float32)
         boxes = np.zeros((self.batch_size, cap, 5), np.float32)
-        for j, k in enumerate(idx):
-            im, bx = self._load(self.annotation_lines[k])
+        seeds = self.rng.integers(0, 2 ** 31 - 1, size=len(idx))
+        jobs = [(self.annotation_lines[k], target, out, int(sd)) for k, sd in zip(idx, seeds)]
+        pool = self._pool()
+        results = list(pool.map(lambda a: self._load(*a), jobs)) if pool else [self._load(*a) for a in jobs]
+        for j, (im, bx) in enumerate(results):
             if len(bx) > self.max_boxes_per_image:
                 raise RuntimeError(f"image has {len(bx)} boxes, capacity {self.max_boxes_per_image}")
             images[j] = im
@@ -156,8 +203,10 @@ class MultiGridDataGenerator:
                 if apply.any():
                     aug.gridmask(img, bx, apply, par)
         img = img / 255.0
-        y = tf_preprocess_true_boxes(bx, self.input_shape, self.anchors, self.num_classes, self.multi_anchor_assign,
-                                     self.grid_shapes)
+        shape = (int(img.shape[1]), int(img.shape[2]))
+        grids = self.grid_shapes if shape == tuple(self.input_shape) else \
+            [(shape[0] // s, shape[1] // s) for s in (32, 16, 8, 4, 2)][:self.num_layers]
+        y = tf_preprocess_true_boxes(bx, shape, self.anchors, self.num_classes, self.multi_anchor_assign, grids)
         return img, bx, y
 
     def __getitem__(self, i):

@@ -12,6 +12,64 @@ import torch
 import torch.distributed as dist
 
 
+def init_distributed(share_gpu=None):
+    """One process per GPU under torch.distributed.run: bind this rank to cuda:LOCAL_RANK BEFORE anything touches the
+    GPU, then create the default process group on RCCL (backend "nccl").  Returns (rank, world, device).  No-op for
+    WORLD_SIZE <= 1.  share_gpu (default: MGD_BENCH_SHARE_GPU=1): rehearsal on a one-GPU box - every rank on cuda:0,
+    gloo for the exchange (RCCL refuses two ranks on one device)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if share_gpu is None:
+        share_gpu = os.environ.get("MGD_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local = 0
+    dev = torch.device("cuda", local)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if share_gpu or not torch.cuda.is_available():
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
+    return rank, world, dev
+
+
+def all_reduce_mean_scalar(value, world):
+    """Mean of a python float over the ranks (validation loss, so that every rank's callbacks see the same number)."""
+    if world <= 1 or not dist.is_initialized():
+        return float(value)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item()) / world
+
+
+def broadcast_flag(flag, world, src=0):
+    """Rank `src`'s boolean for everyone (stop_training): ranks must leave the epoch loop together or the next bucket
+    all-reduce hangs."""
+    if world <= 1 or not dist.is_initialized():
+        return bool(flag)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.broadcast(t, src=src)
+    return bool(t.item())
+
+
+def shard_lines(lines, rank, world):
+    """Rank r's share of the annotation list, truncated so that EVERY rank has the same number of lines
+    (len // world): steps_per_epoch, and with it the sequence of collectives, is then identical across ranks."""
+    if world <= 1:
+        return list(lines)
+    per = len(lines) // world
+    if per == 0:
+        raise ValueError(f"{len(lines)} annotation lines cannot be sharded over {world} ranks")
+    return list(lines[rank:per * world:world])
+
+
 def make_buckets(layer_offsets, n_params, bucket_elems):
     """layer_offsets[i] = first flat index of layer i (ascending).  Returns [(first_layer, begin, end)],
     ordered from the last layers to the first, tiling [0, n_params) exactly."""
@@ -75,6 +133,8 @@ class GradBuckets:
         self.world = world_size
         self.buckets = make_buckets(layer_offsets, grads.numel(), int(bucket_mb * 1e6 / 4))
         self.comm_stream = comm_stream
+        self.after_bucket = None     # hook(bucket_index, begin, end): enqueued on the communication stream BEHIND the
+        #                              bucket's all-reduce (TrainStep: optimiser + weight re-pack of that slice)
         self.reset()
 
     def reset(self, lo=0):
@@ -102,9 +162,14 @@ class GradBuckets:
                 with torch.cuda.stream(self.comm_stream):
                     if self.cabi is not None:
                         self.cabi.all_reduce_sum_(sl)
-                        self._works.append(_Done())
+                        work = _Done()
                     else:
-                        self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
+                        work = dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True)
+                    if self.after_bucket is not None:
+                        work.wait()        # RCCL: a stream dependency (comm stream waits for the collective), no host block
+                        self.after_bucket(self._next - 1, b, e)
+                        work = _Done()
+                    self._works.append(work)
             else:
                 self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
 

@@ -277,6 +277,9 @@ class Network:
         shift as bias, LeakyReLU and the residual add in the conv epilogue - one launch per DarknetConv2D_BN_Leaky
         (models/layers.py:88-95) instead of conv + BN/activation pass.  Opt-in (the unfolded path is the one the parity
         tests pin; folding rounds the scaled weights to bf16 instead of rounding y).  Call again after the weights change."""
+        if on and self.training:
+            raise RuntimeError("fold_bn is an inference-only mode: set training = False first (a training forward through "
+                               "folded convs would leave the raw conv outputs backward needs stale)")
         self.folded = bool(on)
         if not on:
             return
@@ -323,6 +326,8 @@ class Network:
         """images: fp32 CUDA [B,H,W,3] in [0,1].  Returns [y1, y2, y3] raw head tensors (fp32 NHWC)."""
         B, H, W, _ = images.shape
         assert H % 32 == 0 and W % 32 == 0
+        if self.training and getattr(self, "folded", False):
+            raise RuntimeError("training forward with fold_bn on: call fold_bn(False) first")
         A = self.arena(B, H, W)
         A["image"] = images
         self.stats_all.zero_()

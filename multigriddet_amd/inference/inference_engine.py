@@ -1,8 +1,10 @@
 """MultiGridInference with the reference's interface (reference multigriddet/inference/inference_engine.py:27-441):
 `MultiGridInference(config).run()`, `.predict_image(path) -> (annotated_uint8, boxes, classes, scores)`,
-`.predict_batch(images)` (new: batched device path - letterbox on the host, forward + decode + NMS on the GPU with
-no per-image device->host copy before NMS).  Image and directory inputs are supported; 'video' / 'camera' need
-OpenCV, which this image does not have, and raise NotImplementedError."""
+`.predict_batch(images)` / `.predict_frames(uint8 arrays)` (new: batched device path - the uint8 frames are uploaded
+as they are, letterbox + /255 (csrc/preprocess.hip, bit-identical to the reference's PIL letterbox), forward, decode and
+NMS all run on the GPU with no per-image device->host copy before NMS).  Image and directory inputs are supported;
+'video' / 'camera' need OpenCV for capture, which this image does not have, and raise NotImplementedError - a caller
+that has frames (any decoder) feeds predict_frames directly."""
 import os
 import time
 from typing import Any, Dict, List, Tuple
@@ -14,7 +16,7 @@ from ..config.config_loader import ConfigLoader
 from ..config.model_builder import build_model_for_inference
 from ..postprocess import MultiGridDecoder
 from ..utils.anchors import load_anchors, load_classes
-from ..utils.preprocessing import preprocess_image
+from ..utils.preprocessing import DeviceLetterbox, preprocess_image
 
 _EXT = (".jpg", ".jpeg", ".png", ".bmp")
 
@@ -42,19 +44,33 @@ class MultiGridInference:
         self.model = build_model_for_inference(self.full_config, weights_path)
         if self.config.get("fold_bn", False):      # opt-in (not a reference key): BatchNorm folded into the convs
             self.model.fold_bn(True)
+        self.letterbox = DeviceLetterbox(self.input_shape)
+        # "host": the reference's PIL letterbox on the CPU (kept for A/B; results are identical)
+        self.preprocess = self.config.get("preprocess", "device")
 
     def _detect_cfg(self):
         d = self.config.get("detection", {})
         return dict(max_boxes=d.get("max_boxes", 100), confidence=d.get("confidence_threshold", 0.5),
-                    nms_threshold=d.get("nms_threshold", 0.45), nms_method=d.get("nms_method", "diou"))
+                    nms_threshold=d.get("nms_threshold", 0.45), nms_method=d.get("nms_method", "diou"),
+                    per_scale_nms=bool(d.get("per_scale_nms", False)))
 
-    def predict_batch(self, pil_images) -> List[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
-        data = np.concatenate([preprocess_image(im.convert("RGB"), self.input_shape) for im in pil_images], 0)
-        shapes = [tuple(reversed(im.size)) for im in pil_images]
-        outs = self.model(torch.from_numpy(data).cuda(), training=False)
+    def predict_frames(self, frames) -> List[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
+        """frames: list of uint8 RGB arrays [H,W,3] (any sizes).  One device pass for the whole list."""
+        shapes = [tuple(int(v) for v in f.shape[:2]) for f in frames]
+        if self.preprocess == "host":
+            from PIL import Image
+            data = np.concatenate([preprocess_image(Image.fromarray(np.asarray(f, np.uint8)), self.input_shape)
+                                   for f in frames], 0)
+            x = torch.from_numpy(data).cuda()
+        else:
+            x = self.letterbox(frames)
+        outs = self.model(x, training=False)
         ob, osc, ocl, ocn = self.decoder.postprocess_batch(outs, shapes, **self._detect_cfg())
         ob, osc, ocl, ocn = ob.cpu().numpy(), osc.cpu().numpy(), ocl.cpu().numpy(), ocn.cpu().numpy()
-        return [(ob[i, :ocn[i]], ocl[i, :ocn[i]], osc[i, :ocn[i]]) for i in range(len(pil_images))]
+        return [(ob[i, :ocn[i]], ocl[i, :ocn[i]], osc[i, :ocn[i]]) for i in range(len(frames))]
+
+    def predict_batch(self, pil_images) -> List[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
+        return self.predict_frames([np.asarray(im.convert("RGB"), np.uint8) for im in pil_images])
 
     def predict_image(self, image_path: str):
         from PIL import Image, ImageDraw

@@ -139,8 +139,8 @@ class MultiGridDetModel:
         print(f"multigriddet_darknet: {len(self.net.layers)} convs, {self.count_params():,} params "
               f"({self.net.n_params:,} trainable)")
 
-    def save_weights(self, path):
-        out = {}
+    def save_weights(self, path, extra=None):
+        out = dict(extra or {})
         for (cn, bn), p in zip(_keras_names(self.net), self.net.export_keras_style()):
             out[f"{cn}/kernel:0"] = p["kernel"]
             if bn:
@@ -181,6 +181,12 @@ class MultiGridDetModel:
             else:
                 p["bias"] = z[f"{cn}/bias:0"]
         self.net.load_keras_style(plist)
+        if getattr(self.net, "folded", False):
+            if self.net.training:
+                self.net.folded = False
+            else:
+                self.net.fold_bn(True)          # re-fold from the new weights
+        return z
 
 
 def build_multigriddet_darknet(input_shape=(416, 416, 3), num_anchors_per_head=(3, 3, 3), num_classes=80,
@@ -243,14 +249,32 @@ class MultiGridDetTrainModel:
     def count_params(self):
         return self.base.count_params()
 
-    def save_weights(self, path):
-        return self.base.save_weights(path)
+    def save_weights(self, path, include_optimizer=True):
+        """Weights in the Keras-named .npz plus, by default, the optimiser state (`optimizer/m`, `optimizer/v`,
+        `optimizer/step`, `optimizer/kind`, `optimizer/lr`) so that training resumes exactly; the reference's checkpoints
+        hold weights only (trainers/trainer.py:356-368, save_weights_only)."""
+        extra = None
+        if include_optimizer:
+            extra = {"optimizer/m": self.ts.m.cpu().numpy(), "optimizer/step": np.int64(self.ts.step_count),
+                     "optimizer/kind": np.array(self.optimizer.kind), "optimizer/lr": np.float64(float(self.optimizer.learning_rate))}
+            if self.ts.v is not None:
+                extra["optimizer/v"] = self.ts.v.cpu().numpy()
+        return self.base.save_weights(path, extra=extra)
 
-    def load_weights(self, path, **kw):
-        return self.base.load_weights(path, **kw)
+    def load_weights(self, path, load_optimizer=True, **kw):
+        z = self.base.load_weights(path, **kw)
+        if load_optimizer and z is not None and "optimizer/m" in z and str(z["optimizer/kind"]) == self.optimizer.kind \
+                and z["optimizer/m"].shape[0] == self.ts.m.numel():
+            self.ts.m.copy_(torch.from_numpy(z["optimizer/m"]))
+            if self.ts.v is not None and "optimizer/v" in z:
+                self.ts.v.copy_(torch.from_numpy(z["optimizer/v"]))
+            self.ts.step_count = int(z["optimizer/step"])
+        return z
 
     def train_on_batch(self, inputs):
         """inputs: (images, y0, y1, y2) device tensors.  Returns the loss (python float)."""
+        if getattr(self.base.net, "folded", False):
+            self.base.net.fold_bn(False)       # folded images are an inference-only view of the weights
         self.base.net.training = True
         self.ts.lr = float(self.optimizer.learning_rate)
         comp = self.ts.step(inputs[0], y_true=list(inputs[1:]))
@@ -289,6 +313,12 @@ class MultiGridDetTrainModel:
                 vs = validation_steps or len(validation_data)
                 vit = iter(validation_data)
                 logs["val_loss"] = float(np.mean([self.test_on_batch(next(vit)[0]) for _ in range(vs)]))
+            if self.world_size > 1:
+                # every rank's callbacks must see the same numbers (per-replica BN statistics make val_loss differ)
+                from ..dp import all_reduce_mean_scalar
+                for k in ("loss", "val_loss"):
+                    if k in logs:
+                        logs[k] = all_reduce_mean_scalar(logs[k], self.world_size)
             for k, v in logs.items():
                 self.history.setdefault(k, []).append(v)
             if verbose:
@@ -298,6 +328,9 @@ class MultiGridDetTrainModel:
             for cb in callbacks:
                 if hasattr(cb, "on_epoch_end"):
                     cb.on_epoch_end(epoch, logs)
+            if self.world_size > 1:
+                from ..dp import broadcast_flag
+                self.stop_training = broadcast_flag(self.stop_training, self.world_size)
             if self.stop_training:
                 break
         return self

@@ -489,7 +489,7 @@ class LossRunner:
 
 # ------------------------------------------------------------------------------------------- decode / nms
 def make_decode_cfg(anchors, num_classes, input_shape, batch, grid_shapes, confidence, use_softmax=True,
-                    rescore=True, cap=None):
+                    rescore=True, cap=None, tag_scale=False):
     a = _anchor_array(anchors)
     cfg = L.DecodeCfg()
     cfg.L, cfg.A, cfg.C, cfg.B = a.shape[0], a.shape[1], num_classes, batch
@@ -503,6 +503,7 @@ def make_decode_cfg(anchors, num_classes, input_shape, batch, grid_shapes, confi
     cfg.use_softmax, cfg.rescore = int(use_softmax), int(rescore)
     cfg.confidence = float(confidence)
     cfg.cap = int(cap if cap is not None else tot)
+    cfg.tag_scale = int(bool(tag_scale))
     return cfg
 
 
@@ -526,7 +527,11 @@ def decode(cfg, y_pred, image_hw):
 NMS_METHODS = {"standard": 0, "cluster": 0, "iou": 0, "diou": 1, "soft": 2}
 
 
-def nms(boxes, scores, cls, count, image_hw, method="diou", threshold=0.5, max_boxes=100, return_xyxy=True):
+NMS_PER_SCALE = 0x100
+
+
+def nms(boxes, scores, cls, count, image_hw, method="diou", threshold=0.5, max_boxes=100, return_xyxy=True,
+        per_scale=False):
     """method: 'standard' / 'cluster' (IoU), 'diou', 'soft' (SoftNMS sigma 0.5, score threshold 1e-3), or 'wbf'
     (Weighted Boxes Fusion with iou_thr = threshold).  Batched: one block per image."""
     lib = L.load()
@@ -544,7 +549,8 @@ def nms(boxes, scores, cls, count, image_hw, method="diou", threshold=0.5, max_b
                             max_boxes, L.ptr(image_hw), int(return_xyxy), L.ptr(ob), L.ptr(osc), L.ptr(ocl), L.ptr(ocn),
                             L.ptr(ws), C.c_size_t(need), L.stream_ptr()), "wbf")
     else:
-        L.check(lib.mgd_nms(L.ptr(boxes), L.ptr(scores), L.ptr(cls), L.ptr(count), B, cap, NMS_METHODS[method],
+        L.check(lib.mgd_nms(L.ptr(boxes), L.ptr(scores), L.ptr(cls), L.ptr(count), B, cap,
+                            NMS_METHODS[method] | (NMS_PER_SCALE if per_scale else 0),
                             C.c_float(threshold), max_boxes, L.ptr(image_hw), int(return_xyxy), L.ptr(ob), L.ptr(osc),
                             L.ptr(ocl), L.ptr(ocn), L.ptr(ws), C.c_size_t(need), L.stream_ptr()), "nms")
     return ob, osc, ocl, ocn

@@ -34,7 +34,7 @@ class MultiGridDecoder:
         return torch.from_numpy(np.ascontiguousarray(t, np.float32)).cuda()
 
     def postprocess_batch(self, outputs: Sequence, image_shapes, max_boxes=100, confidence=0.1, nms_threshold=0.5,
-                          nms_method="diou", return_xyxy=True, use_wbf=False):
+                          nms_method="diou", return_xyxy=True, use_wbf=False, per_scale_nms=False):
         """outputs: L tensors [B,g,g,F]; image_shapes: [B,2] (h,w).  Returns device tensors
         (boxes [B,max_boxes,4], scores [B,max_boxes], classes [B,max_boxes], count [B])."""
         if len(outputs) != self.num_layers:
@@ -47,10 +47,13 @@ class MultiGridDecoder:
         grids = [(int(o.shape[1]), int(o.shape[2])) for o in outs]
         ihw = torch.as_tensor(np.asarray(image_shapes, np.float32).reshape(B, 2)).cuda()
         cfg = ops.make_decode_cfg(self.anchors, self.num_classes, self.input_shape, B, grids, confidence,
-                                  use_softmax=self.use_softmax, rescore=self.rescore_confidence)
+                                  use_softmax=self.use_softmax, rescore=self.rescore_confidence,
+                                  tag_scale=per_scale_nms)
+        if per_scale_nms and (use_wbf or nms_method == "soft"):
+            raise ValueError("per_scale_nms applies to the greedy NMS methods ('diou', 'cluster')")
         b, s, c, n = ops.decode(cfg, outs, ihw)
         return ops.nms(b, s, c, n, ihw, method="wbf" if use_wbf else nms_method, threshold=nms_threshold,
-                       max_boxes=max_boxes, return_xyxy=return_xyxy)
+                       max_boxes=max_boxes, return_xyxy=return_xyxy, per_scale=per_scale_nms)
 
     def postprocess(self, multigriddet_outputs, image_shape, model_image_size, max_boxes: int = 100,
                     confidence: float = 0.1, nms_threshold: float = 0.5, use_iol: bool = True,

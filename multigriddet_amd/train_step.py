@@ -45,6 +45,10 @@ class TrainStep:
             cabi = CabiComm(dist.get_rank(), world_size, dev)       # the library's own RCCL binding (mgd_comm_*)
         self.dp = GradBuckets(net.grads, [cv.off_w for cv in net.layers], world_size, bucket_mb, self.comm_stream,
                               producer_streams=(net.wg_stream,), cabi_comm=cabi)
+        # N > 1: the optimiser and the weight re-pack of a bucket ride on the communication stream right behind that
+        # bucket's all-reduce, under the rest of backward - no serial optimiser tail after the last collective
+        self.bucket_optimizer = True
+        self._bucket_packs = {}
         self.main_stream = torch.cuda.Stream(device=dev, priority=-1)
         # hipGraph replay of the whole step (single process, Adam/AdamW): see enable_graph()
         self.use_graph = False
@@ -143,10 +147,16 @@ class TrainStep:
         comp = runner.run(y_true, outs, grad_bf16=douts)
         if self.world > 1:
             rng_ = net.trainable_range()
-            self.dp.reset(lo=rng_[0] if rng_ else 0)
+            lo = rng_[0] if rng_ else 0
+            self.dp.reset(lo=lo)
+            per_bucket = self.bucket_optimizer and rng_ is not None
+            self.dp.after_bucket = (lambda k, b, e: self._bucket_update(k, b, e, dev_hyper)) if per_bucket else None
             net.backward(douts, on_layer_done=self.dp.on_layer_done)
-            self.dp.finish()      # makes the compute stream wait for the collectives
-            self.apply_optimizer(dev_hyper=dev_hyper)
+            self.dp.finish()      # makes the compute stream wait for the collectives (and the per-bucket updates)
+            if per_bucket:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+            else:
+                self.apply_optimizer(dev_hyper=dev_hyper)
         elif self._early_ok():
             # Adam + re-pack of the layers whose gradients are final early (stage 5 + head: two thirds of the parameters,
             # then stage 4: another quarter) go to the weight-gradient side stream in the middle of backward - HBM-bound
@@ -172,6 +182,18 @@ class TrainStep:
             net.backward(douts)
             self.apply_optimizer(dev_hyper=dev_hyper)
         return comp
+
+    def _bucket_update(self, k, b, e, dev_hyper):
+        """Runs on the communication stream behind bucket k's all-reduce: optimiser over the summed slice [b, e) and the
+        bf16 re-pack of the convs whose weights lie in it."""
+        net = self.net
+        self._optimizer_range(b, e, dev_hyper)
+        pk = self._bucket_packs.get((k, b))
+        if pk is None:
+            pairs = [(cv.pk, cv.wpack) for cv in net.layers if cv.pk is not None and b <= cv.off_w < e]
+            pk = self._bucket_packs[(k, b)] = ops.PackBatch(pairs, net.device) if pairs else False
+        if pk:
+            pk.run()
 
     def _early_ok(self):
         net = self.net

@@ -87,8 +87,9 @@ class MultiGridTrainer:
         self.callbacks = []
         self.model_config = ConfigLoader.load_config(config["model_config"])
         self.full_config = ConfigLoader.merge_configs(self.model_config, config)
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.rank = int(os.environ.get("RANK", "0"))
+        # one process per GPU: bind to cuda:LOCAL_RANK and create the RCCL process group before anything touches the GPU
+        from ..dp import init_distributed
+        self.rank, self.world, self.device = init_distributed()
         print("=" * 80 + "\nMultiGridDet Trainer Initialized (MI355X / gfx950)\n" + "=" * 80)
 
     def setup_data(self):
@@ -100,7 +101,11 @@ class MultiGridTrainer:
         train_lines = load_annotation_lines(dc["train_annotation"], shuffle=True)
         val_lines = load_annotation_lines(dc["val_annotation"], shuffle=False)
         if self.world > 1:
-            train_lines = train_lines[self.rank::self.world]
+            from ..dp import shard_lines
+            import torch.distributed as dist
+            box = [train_lines]                       # rank 0's shuffle for everyone, then equal-length shards
+            dist.broadcast_object_list(box, src=0)
+            train_lines = shard_lines(box[0], self.rank, self.world)
         self.input_shape = tuple(preset["input_shape"][:2])
         ac = tc.get("augmentation", {})
         common = dict(batch_size=tc["batch_size"], input_shape=self.input_shape, anchors=self.anchors,

@@ -143,8 +143,25 @@ def convert_to_xyxy(boxes, image_shape):
     return np.floor(out + 0.5).astype("int32")
 
 
+def greedy_nms_per_scale(boxes, scores, seg, thr, method="diou"):
+    """The build's per-scale option (no reference counterpart; multigrid_decode.py:98 concatenates the scales first):
+    global score order, a kept box suppresses only later boxes of its own scale."""
+    order = np.argsort(scores)[::-1]
+    keep = []
+    metric = _diou_1vN if method == "diou" else (lambda b, bs: _iou_1vN(b, bs)[0])
+    while len(order) > 0:
+        cur = order[0]
+        keep.append(cur)
+        if len(order) == 1:
+            break
+        rest = order[1:]
+        m = metric(boxes[cur], boxes[rest])
+        order = rest[(m < thr) | (seg[rest] != seg[cur])]
+    return np.array(keep, dtype=np.int64)
+
+
 def postprocess(outputs, anchors, num_classes, input_shape, image_shape, model_image_size, max_boxes=100,
-                confidence=0.1, nms_threshold=0.5, nms_method="diou", return_xyxy=True):
+                confidence=0.1, nms_threshold=0.5, nms_method="diou", return_xyxy=True, per_scale=False):
     """MultiGridDecoder.postprocess (:347-395) for nms_method in {'diou','cluster','soft'} (cluster
     == standard IoU greedy in the reference, nms.py:320-385)."""
     pred = decode_predictions(outputs, anchors, num_classes, input_shape)
@@ -155,7 +172,12 @@ def postprocess(outputs, anchors, num_classes, input_shape, image_shape, model_i
     if len(pos[0]) == 0:
         return np.array([]), np.array([]), np.array([])
     boxes, classes, scores = boxes[pos], classes[pos], conf[pos]
-    if nms_method == "soft":
+    if per_scale:
+        cells = [int(np.prod(o.shape[1:3])) for o in outputs]
+        seg_all = np.concatenate([np.full(n, l) for l, n in enumerate(cells)])[None, :]
+        keep = greedy_nms_per_scale(boxes, scores, seg_all[pos], nms_threshold, "diou" if nms_method == "diou" else "iou")
+        boxes, classes, scores = boxes[keep], classes[keep].astype("int32"), scores[keep]
+    elif nms_method == "soft":
         mask, soft = soft_nms(boxes, scores)
         boxes, classes, scores = boxes[mask], classes[mask].astype("int32"), soft[mask]
     else:

@@ -904,3 +904,38 @@ def test_decode_nms_batched_matches_single(dev):
         got = ob[i, :k].cpu().numpy()
         assert np.abs(got - rb).max() <= 1 and (got == rb).mean() > 0.98
         assert np.array_equal(ocl[i, :k].cpu().numpy(), rc)
+
+
+def test_per_scale_nms_option_vs_oracle(dev):
+    """north-star "per-scale NMS" (BASELINE config 5): one launch, global ranking, suppression only inside a scale.  No
+    reference counterpart (multigrid_decode.py:98 concatenates first) - checked against the oracle's restatement of the
+    rule, and against the default path to show it is a different (weaker) suppression."""
+    from multigriddet_amd.postprocess import MultiGridDecoder
+    from oracle import decode as odec
+    size, B = 608, 4
+    grids = [(19, 19), (38, 38), (76, 76)]
+    rng = np.random.default_rng(31)
+    heads = [(2.0 * rng.standard_normal((B, g[0], g[1], 88))).astype(np.float32) for g in grids]
+    shapes = [(480, 640), (608, 608), (300, 500), (720, 1280)]
+    dec = MultiGridDecoder(coco_anchors(), 80, (size, size))
+    for method in ("diou", "cluster"):
+        ob, osc, ocl, ocn = dec.postprocess_batch(heads, shapes, max_boxes=100, confidence=0.1, nms_threshold=0.45,
+                                                  nms_method=method, per_scale_nms=True)
+        ob0, _, _, ocn0 = dec.postprocess_batch(heads, shapes, max_boxes=100, confidence=0.1, nms_threshold=0.45,
+                                                nms_method=method)
+        torch.cuda.synchronize()
+        differs = False
+        for b in range(B):
+            rb, rc, rs = odec.postprocess([h[b:b + 1] for h in heads], coco_anchors(), 80, (size, size), shapes[b],
+                                          (size, size), confidence=0.1, nms_threshold=0.45, nms_method=method,
+                                          per_scale=True)
+            k = int(ocn[b])
+            assert k == len(rb)
+            assert np.array_equal(ob[b, :k].cpu().numpy(), rb)
+            assert np.array_equal(ocl[b, :k].cpu().numpy(), rc)
+            np.testing.assert_allclose(osc[b, :k].cpu().numpy(), rs, rtol=1e-5)
+            assert ocl[b, :k].max() < 80                      # the scale tag is stripped from the class ids
+            differs |= not torch.equal(ob[b], ob0[b])
+        assert differs
+    with pytest.raises(ValueError):
+        dec.postprocess_batch(heads, shapes, nms_method="soft", per_scale_nms=True)

@@ -89,3 +89,45 @@ def test_cli_missing_config_returns_1():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--config", "/nonexistent.yaml"],
                          capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 1 and "Config file not found" in out.stdout
+
+
+def test_letterbox_matches_reference_fixture():
+    """G4: utils/preprocessing.letterbox_resize / preprocess_image against the reference's own outputs
+    (tests/golden/letterbox.npz, generated by tests/golden/make_golden_letterbox.py from
+    /root/reference/multigriddet/utils/preprocessing.py:12-90)."""
+    import os
+    from PIL import Image
+    from conftest import GOLDEN
+    from multigriddet_amd.utils.preprocessing import letterbox_resize, preprocess_image, letterbox_geometry
+    g = np.load(os.path.join(GOLDEN, "letterbox.npz"))
+    for i in range(int(g["n"])):
+        pil = Image.fromarray(g[f"img{i}"])
+        mh, mw = (int(v) for v in g[f"model_hw{i}"])
+        boxed, size, off = letterbox_resize(pil, (mw, mh), return_padding_info=True)
+        assert np.array_equal(np.asarray(boxed, np.uint8), g[f"boxed{i}"])
+        assert (size[0], size[1], off[0], off[1]) == tuple(int(v) for v in g[f"pad{i}"])
+        data = preprocess_image(pil, (mh, mw))
+        assert data.dtype == np.float32 and data.shape == (1, mh, mw, 3)
+        assert np.array_equal(data[0], g[f"boxed{i}"].astype(np.float32) / np.float32(255.0))
+        nh, nw, dy, dx = letterbox_geometry(g[f"img{i}"].shape[:2], (mh, mw))
+        assert (nw, nh, dx, dy) == tuple(int(v) for v in g[f"pad{i}"])
+
+
+def test_resample_tables_reproduce_pil_bicubic_exactly():
+    """The coefficient tables the device letterbox consumes: driving PIL's two integer passes with them (oracle/preprocess.py)
+    gives PIL's Image.resize(BICUBIC) bit for bit, for up- and down-scaling, and the reference's letterbox fixture."""
+    import os
+    from PIL import Image
+    from conftest import GOLDEN
+    from multigriddet_amd.utils.preprocessing import resample_tables, letterbox_geometry
+    from oracle import preprocess as op
+    rng = np.random.default_rng(5)
+    for (h, w), (nh, nw) in [((37, 53), (45, 64)), ((80, 60), (64, 48)), ((33, 100), (10, 31)), ((20, 20), (20, 20)),
+                             ((17, 9), (60, 32))]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BICUBIC), np.uint8)
+        assert np.array_equal(op.resize_u8(img, (nh, nw), resample_tables), ref), ((h, w), (nh, nw))
+    g = np.load(os.path.join(GOLDEN, "letterbox.npz"))
+    for i in range(int(g["n"])):
+        mh, mw = (int(v) for v in g[f"model_hw{i}"])
+        assert np.array_equal(op.letterbox(g[f"img{i}"], (mh, mw), resample_tables, letterbox_geometry), g[f"boxed{i}"])
