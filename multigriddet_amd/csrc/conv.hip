@@ -759,6 +759,179 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// v8, "resident patch" form of the 3x3 stride-1 gather-GEMM (forward and stride-1 data gradient) for Ci >= 64.
+//
+// The gather-GEMMs above stream BOTH operands through LDS-DMA every K-step: 32 KB per 128 x 128 x 64 step, and a CU takes
+// in ~32 B/clk from L2 (MI355X_MICROARCH.md: 66-73 GB/s per CU), i.e. >= 1000 cycles of DMA against 512 cycles of MFMA.
+// A 3x3 conv re-reads every input pixel nine times; here the haloed input patch of the block's 128 output pixels is
+// staged in LDS ONCE (all channels of a pass, 64-channel chunks, same XOR-swizzled 128-byte rows as the ring) and the
+// nine taps read it at shifted pixel indices - the only per-K-step DMA left is the 16 KB weight tile, which runs through
+// an NST-deep ring with counted vmcnt.  Out-of-image pixels come from a zero page when the patch is loaded: no per-tap
+// masks, no zero fix-ups in the loop.
+//
+// Pixel tile: 8 MFMA n-tiles of 16 pixels, an n-tile being NR rows x NC columns (NC = 16 / 8 / 4 chosen so that the map
+// width wastes least), stacked vertically: TH = 8*NR rows x TW = NC columns.  Rows run over the whole batch in "stacked"
+// coordinates Rs = n*(H+1) + h: one virtual zero row separates consecutive images (it is the bottom padding of image n and
+// the top padding of image n+1 at once), so tiles may span images and maps of any height tile without per-image waste.
+// K order: pass-major (a pass = up to 4 chunks of 64 input channels resident at once), then tap, then chunk.
+struct PgArgs {
+  int NC, NR, TH, TW, PW, PP, PP8;   // n-tile shape, tile, patch width, patch pixels, ceil(PP / 8)
+  int S;                             // stacked rows N*(H+1) - 1
+  int tilesW, tilesR;
+  int nch, cpp, npass;               // 64-channel chunks, chunks per pass, passes
+};
+
+template <int WP, int NST>
+__global__ __launch_bounds__(128 * WP) void conv_pgemm_kernel(GemmArgs a, PgArgs g) {
+  constexpr int WC = 2, MT = 4, NT = 8 / WP;
+  using Epi = GemmEpilogue<WC, WP, MT, NT>;
+  constexpr int BNC = 128, NTHR = 128 * WP, NW = NTHR / 64;
+  constexpr int RPR = NTHR / 8;                 // ring rows covered by one LDS-DMA round of the block
+  constexpr int WCH = BNC / RPR;                // weight glds per thread per stage (4 or 2)
+  constexpr int STAGE = BNC * ROWB;             // 16 KB
+  constexpr int MAXPG = (26 + NW - 1) / NW;     // patch pieces (8 pixels x 128 B) per wave per chunk, PP8 <= 26
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* patch = smem + NST * STAGE;
+  long long* row_dst = (long long*)(patch + (size_t)g.cpp * g.PP8 * 1024);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave / WP, wp = wave % WP;
+  const int L = xcd_remap(blockIdx.x, a.nblk);
+  const int tc = L % a.tilesC, tp = L / a.tilesC;
+  const int co0 = tc * BNC;
+  const int tcol = tp % g.tilesW, trow = tp / g.tilesW;
+  const int R0 = trow * g.TH, c0 = tcol * g.TW;
+  const int H1 = a.Hs + 1;
+
+  if (tid < 128) {
+    const int nt = tid >> 4, f = tid & 15;
+    const int Rs = R0 + nt * g.NR + f / g.NC, w = c0 + f % g.NC;
+    const int n = Rs / H1, h = Rs - n * H1;
+    long long off = -1;
+    if (Rs < g.S && h < a.Hs && w < a.Ws) off = (((long long)n * a.Hs + h) * a.Ws + w) * a.Co;
+    row_dst[tid] = off;
+  }
+
+  // ---- patch pieces of this wave: piece pg covers patch pixels 8*pg .. 8*pg+7 (one 1-KiB LDS-DMA instruction per chunk)
+  unsigned poff[MAXPG];
+  unsigned pval = 0;
+#pragma unroll
+  for (int j = 0; j < MAXPG; ++j) {
+    const int pg = wave + j * NW;
+    const int pp = pg * 8 + (lane >> 3);
+    const int pr = pp / g.PW, pc = pp - pr * g.PW;
+    const int Rs = R0 + pr - 1, cin = c0 + pc - 1;
+    const int n = Rs / H1, h = Rs - n * H1;
+    const bool v = pg < g.PP8 && pp < g.PP && Rs >= 0 && Rs < g.S && h < a.Hs && (unsigned)cin < (unsigned)a.Ws;
+    poff[j] = v ? (unsigned)(((((long long)n * a.Hs + h) * a.Ws + cin) * a.Ci) * 2) + (unsigned)(((lane & 7) ^ (pp & 7)) << 4) : 0u;
+    if (v) pval |= 1u << j;
+  }
+  const char* xbase = (const char*)a.src;
+  const char* wbase = (const char*)a.wpk;
+  const void* zero = (const void*)g_zero_page;
+  auto issue_patch = [&](int pass) {
+    for (int c = 0; c < g.cpp; ++c) {
+      const unsigned coff = (unsigned)((pass * g.cpp + c) * 128);
+#pragma unroll
+      for (int j = 0; j < MAXPG; ++j) {
+        const int pg = wave + j * NW;
+        if (pg < g.PP8) {
+          const void* s = ((pval >> j) & 1u) ? (const void*)(xbase + (size_t)poff[j] + coff) : zero;
+          glds16(s, patch + ((size_t)c * g.PP8 + pg) * 1024);
+        }
+      }
+    }
+  };
+
+  // ---- weight ring: thread -> slot (tid & 7) of rows (tid >> 3) + RPR i, source chunk kc = slot ^ (row & 7)
+  const int rlo = tid >> 3;
+  unsigned woff[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; ++i)
+    woff[i] = (unsigned)(((long long)(co0 + rlo + RPR * i) * a.K_pad + (((tid & 7) ^ (rlo & 7)) * 8)) * 2);
+  const int nk = 9 * g.nch, npk = 9 * g.cpp;     // K-steps in total / per pass
+  // issue cursor (runs NST-1 steps ahead of the compute cursor): pass, tap, chunk -> K offset (tap*Ci + chunk*64) * 2 bytes
+  int ip = 0, it = 0, ic = 0;
+  auto issue_w = [&](int slot) {
+    const unsigned kb = (unsigned)((it * a.Ci + (ip * g.cpp + ic) * 64) * 2);
+    unsigned char* wb = smem + slot * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) glds16(wbase + woff[i] + kb, wb + i * (RPR * ROWB));
+    if (++ic == g.cpp) { ic = 0; if (++it == 9) { it = 0; ++ip; } }
+  };
+
+  Epi epi;
+  epi.prefetch(a, row_dst, co0, tid);            // contains the __syncthreads that publishes row_dst
+
+  issue_patch(0);
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue_w(s);
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  int wro[MT], xpix[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) wro[m] = lds_off((wc * MT + m) * 16 + fr, fq);
+#pragma unroll
+  for (int n = 0; n < NT; ++n) xpix[n] = ((wp * NT + n) * g.NR + fr / g.NC) * g.PW + fr % g.NC;
+
+  int ks = 0;
+  for (int pass = 0; pass < g.npass; ++pass) {
+    if (pass > 0) {
+      // every wave has left the previous pass's patch (trailing barrier of its last K-step): reload, then wait for
+      // everything (the ring stages issued earlier are older in the counter and have landed as well)
+      issue_patch(pass);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+    int tap = 0, c = 0;
+    for (int kp = 0; kp < npk; ++kp, ++ks) {
+      const int pending = min(NST - 2, nk - 1 - ks);
+      if (NST >= 4 && pending >= 2) wait_vmcnt<2 * WCH>();
+      else if (NST >= 3 && pending >= 1) wait_vmcnt<WCH>();
+      else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (ks + NST - 1 < nk) issue_w((ks + NST - 1) % NST);
+      const unsigned char* sb = smem + (ks % NST) * STAGE;
+      const int dh = (int)((a.tapcode >> (4 * tap)) & 3), dw = (int)((a.tapcode >> (4 * tap + 2)) & 3);   // already +1
+      const int toff = dh * g.PW + dw;
+      const unsigned char* pb = patch + (size_t)c * g.PP8 * 1024;
+      int xro[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int pp = xpix[n] + toff;
+        xro[n] = pp * ROWB + ((fq ^ (pp & 7)) << 4);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 wf[MT], xf[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(sb + (wro[m] ^ (kk << 6)));
+#pragma unroll
+        for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(pb + (xro[n] ^ (kk << 6)));
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
+      }
+      if (++c == g.cpp) { c = 0; ++tap; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // all fragment reads of this pass's patch are done
+  }
+  __syncthreads();
+  epi.run(a, acc, smem, row_dst, co0, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
 // "Patch" form of the 3x3 gather-GEMM for the thin early layers (CI, CO <= 64: all nine taps of the weights fit in
 // LDS).  The v2 kernel walks K = 9*CI in 64-deep steps and is bound by one LDS-DMA round trip per step (1.63 us), i.e.
 // by nothing the layer itself needs: the input is re-read nine times through L2.  Here a persistent block keeps the
@@ -1999,6 +2172,46 @@ int launch_gemm2(GemmArgs& a, hipStream_t st) {
 }
 
 
+template <int WP, int NST>
+int launch_pgemm(GemmArgs& a, const PgArgs& g, hipStream_t st) {
+  a.tilesC = a.Co_pad / 128;
+  a.nblk = a.tilesC * g.tilesR * g.tilesW;
+  size_t lds = (size_t)NST * 128 * ROWB + (size_t)g.cpp * g.PP8 * 1024 + 128 * 8;
+  auto k = conv_pgemm_kernel<WP, NST>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(128 * WP), lds, st, a, g);
+  return 0;
+}
+
+// geometry of the resident-patch form for an H x W map; false if the layer does not qualify
+bool pgemm_geometry(const mgd_conv_desc* d, PgArgs* g) {
+  bool std9 = d->ntaps == 9 && d->in_stride == 1 && d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 &&
+              d->Hs == d->Hg && d->Ws == d->Wg && d->Hd == d->Hg && d->Wd == d->Wg && d->Ci % 64 == 0 && d->Ci >= 64 &&
+              d->K_pad == 9 * d->Ci && d->Co_pad % 128 == 0 && !d->dst_f32 && d->Wg >= 4 && d->Hg >= 2;
+  for (int t = 0; t < 9 && std9; ++t) std9 = d->dh[t] == t / 3 - 1 && d->dw[t] == t % 3 - 1;
+  if (!std9) return false;
+  int best = 16;
+  double beste = 0;
+  for (int nc = 16; nc >= 4; nc >>= 1) {
+    double e = (double)d->Wg / ((double)cdiv(d->Wg, nc) * nc);
+    if (e > beste + 1e-9) { beste = e; best = nc; }
+  }
+  g->NC = best; g->NR = 16 / best; g->TH = 8 * g->NR; g->TW = best;
+  g->PW = g->TW + 2; g->PP = g->PW * (g->TH + 2); g->PP8 = (g->PP + 7) / 8;
+  long long S = (long long)d->N * (d->Hg + 1) - 1;
+  if (S >= (1ll << 30)) return false;
+  g->S = (int)S;
+  g->tilesW = cdiv(d->Wg, g->TW); g->tilesR = cdiv(S, g->TH);
+  g->nch = d->Ci / 64; g->cpp = g->nch < 4 ? g->nch : 4;
+  if (g->nch % g->cpp) return false;
+  g->npass = g->nch / g->cpp;
+  return g->PP8 <= 26;
+}
+
 template <int WC, int WP, int MT, int NT, int NS>
 int launch_gemm6(GemmArgs& a, hipStream_t st) {
   constexpr int BNC = WC * MT * 16, BMP = WP * NT * 16;
@@ -2185,6 +2398,20 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     if (variant == 3 && patch && std9p && d->Ci == 64 && d->Co == 32 && d->Co_pad == 32 && d->in_stride == 1) {
       launch_patch<64, 32, 1>(a, st);             // the stride-1 data gradient of a 32 -> 64 layer
       MGD_CHECK_LAUNCH("conv_gather_gemm(patch)");
+      return MGD_OK;
+    }
+  }
+  // resident-patch form for the 3x3 stride-1 layers with Ci >= 64 (forward and stride-1 data gradient)
+  {
+    static int pgemm = -1;
+    if (pgemm < 0) { const char* e = getenv("MGD_PGEMM"); pgemm = e ? atoi(e) : 1; }
+    PgArgs g;
+    if (variant == 3 && pgemm && pgemm_geometry(d, &g)) {
+      const size_t patchb = (size_t)g.cpp * g.PP8 * 1024;
+      if (patchb + 2 * 16384 + 1024 <= 80 * 1024) launch_pgemm<2, 2>(a, g, st);          // two 4-wave blocks per CU
+      else if (patchb + 4 * 16384 + 1024 <= 160 * 1024) launch_pgemm<4, 4>(a, g, st);    // one 8-wave block per CU
+      else launch_pgemm<4, 3>(a, g, st);
+      MGD_CHECK_LAUNCH("conv_gather_gemm(resident patch)");
       return MGD_OK;
     }
   }

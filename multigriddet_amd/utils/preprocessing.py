@@ -106,7 +106,7 @@ class DeviceLetterbox:
         if out is None:
             out = torch.empty(B, hm, wm, 3, dtype=torch.float32, device=self.device)
         for i, f in enumerate(frames):
-            fr = f if isinstance(f, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(f, np.uint8))
+            fr = f if isinstance(f, torch.Tensor) else torch.from_numpy(np.array(f, dtype=np.uint8, order="C"))
             fr = fr.to(self.device, torch.uint8).contiguous()
             h, w = int(fr.shape[0]), int(fr.shape[1])
             nh, nw, dy, dx, ksx, ksy, (kx, bx, ky, by) = self._get(h, w)

@@ -56,6 +56,9 @@ CONV_CASES = [
     (2, 44, 40, 64, 128, 3, 2),          # patch-form weight gradient: Ci = 64, stride 2, ragged tiles
     (2, 76, 76, 128, 256, 3, 1),         # kernel-row weight gradient (Ci >= 128): full tiles
     (2, 21, 37, 256, 128, 3, 1),         # kernel-row weight gradient: non-square, ragged tiles, two Ci slices
+    (2, 19, 19, 512, 1024, 3, 1),        # resident-patch gather-GEMM: two passes of 4 chunks (dgrad: four), 4x4 n-tiles
+    (3, 5, 7, 64, 128, 3, 1),            # resident-patch gather-GEMM: map smaller than one tile, three images in it
+    (2, 38, 38, 256, 512, 3, 1),         # resident-patch gather-GEMM: 2x8 n-tiles, tiles spanning the image boundary
 ]
 
 
