@@ -759,7 +759,8 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// v8, "resident patch" form of the 3x3 stride-1 gather-GEMM (forward and stride-1 data gradient) for Ci >= 64.
+// "Resident patch" form of the 3x3 stride-1 gather-GEMM (forward and stride-1 data gradient) for Ci >= 64 (opt-in:
+// MGD_PGEMM=2; measured slower than the gather-GEMMs above at batch 16).
 //
 // The gather-GEMMs above stream BOTH operands through LDS-DMA every K-step: 32 KB per 128 x 128 x 64 step, and a CU takes
 // in ~32 B/clk from L2 (MI355X_MICROARCH.md: 66-73 GB/s per CU), i.e. >= 1000 cycles of DMA against 512 cycles of MFMA.
@@ -779,156 +780,305 @@ struct PgArgs {
   int S;                             // stacked rows N*(H+1) - 1
   int tilesW, tilesR;
   int nch, cpp, npass;               // 64-channel chunks, chunks per pass, passes
+  int pbytes;                        // persistent form: bytes of one patch buffer
 };
 
-template <int WP, int NST>
-__global__ __launch_bounds__(128 * WP) void conv_pgemm_kernel(GemmArgs a, PgArgs g) {
-  constexpr int WC = 2, MT = 4, NT = 8 / WP;
+// keeps a wave-uniform value in an SGPR and opaque to the compiler: it can then neither be re-loaded from the kernel
+// argument segment inside the K-loop (a scalar load there forces s_waitcnt lgkmcnt(0) in front of the MFMAs and with it
+// the just-issued fragment reads of the NEXT step) nor folded back into a longer expression
+// keeps a wave-uniform value in an SGPR and opaque to the compiler: it can then neither be re-loaded from the kernel
+// argument segment inside the K-loop (a scalar load there forces s_waitcnt lgkmcnt(0) in front of the MFMAs and with it
+// the just-issued fragment reads of the NEXT step) nor folded back into a longer expression
+// ds_read_b128 the compiler does not see: it adds no s_waitcnt for it (hipcc waits lgkmcnt(0) in front of the MFMAs of the
+// CURRENT step once the reads of the NEXT step are in flight), so completion is waited for by hand (lgkmcnt(0) at the top of
+// the next half-iteration, then touch8() on every destination before its first consumer)
+__device__ __forceinline__ void lds_read16_asm(bf16x8& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "+v"(dst) : "v"(addr));     // "+v": the set keeps its registers around the loop
+}
+__device__ __forceinline__ void touch8(bf16x8& v) { asm volatile("" : "+v"(v)); }
+
+__device__ __forceinline__ int sgpr(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent kernel.  A one-tile-per-block version spent more than half of a block's life in its prologue on the 76x76
+// layers (stamps): the patch (46 KB, first touch from HBM) has to land before the first MFMA and a CU runs one block at a
+// time.  Here a block stays resident and walks its tiles; a work item is one pass
+// of one tile (<= 2 chunks = 128 input channels, 18 K-steps) and the patch of item i+1 is prefetched into the other of two
+// patch buffers while item i computes.  Waves 0-3 stream the weight ring, waves 4-7 the patches, so each wave's vmcnt queue
+// holds one kind of LDS-DMA only (ring waves: counted waits per stage; patch waves: one wait before the barrier that ends
+// the item); all eight waves compute.  The weight ring and the one-step-ahead fragment reads run on across item and tile
+// boundaries; the epilogue of a tile borrows the patch buffer the tile has just left.
+template <int NST, bool STAMP = false>
+__global__ __launch_bounds__(512) void conv_pgemm2_kernel(GemmArgs a, PgArgs g) {
+  constexpr int WC = 2, WP = 4, MT = 4, NT = 2;
   using Epi = GemmEpilogue<WC, WP, MT, NT>;
-  constexpr int BNC = 128, NTHR = 128 * WP, NW = NTHR / 64;
-  constexpr int RPR = NTHR / 8;                 // ring rows covered by one LDS-DMA round of the block
-  constexpr int WCH = BNC / RPR;                // weight glds per thread per stage (4 or 2)
-  constexpr int STAGE = BNC * ROWB;             // 16 KB
-  constexpr int MAXPG = (26 + NW - 1) / NW;     // patch pieces (8 pixels x 128 B) per wave per chunk, PP8 <= 26
+  constexpr int BNC = 128, STAGE = BNC * ROWB, WCH = 4, MAXPG = 7;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* patch = smem + NST * STAGE;
-  long long* row_dst = (long long*)(patch + (size_t)g.cpp * g.PP8 * 1024);
+  const int cpp = sgpr(g.cpp), PW = sgpr(g.PW), npass = sgpr(g.npass);
+  const int pchunk = sgpr(g.PP8 * 1024);
+  const int PB = sgpr(g.pbytes);                                  // >= cpp * pchunk and >= the epilogue's LDS tile
+  unsigned char* pbuf = smem + NST * STAGE;                       // two patch buffers of PB bytes
+  int* rin = (int*)(pbuf + 2 * (size_t)PB);                       // [2][40]: first pixel index of each patch row, or -1
+  long long* row_dst = (long long*)(rin + 80);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool ringw = wave < 4;
   const int wc = wave / WP, wp = wave % WP;
-  const int L = xcd_remap(blockIdx.x, a.nblk);
-  const int tc = L % a.tilesC, tp = L / a.tilesC;
-  const int co0 = tc * BNC;
-  const int tcol = tp % g.tilesW, trow = tp / g.tilesW;
-  const int R0 = trow * g.TH, c0 = tcol * g.TW;
-  const int H1 = a.Hs + 1;
+  const int H1 = a.Hs + 1, PH = g.TH + 2;
+  const int ntiles = a.nblk, nblocks = gridDim.x;
+  const int lb = xcd_remap(blockIdx.x, nblocks);                   // neighbouring logical ids share an XCD (and its L2)
+  const int mytiles = (ntiles - lb + nblocks - 1) / nblocks;       // tiles lb, lb + nblocks, ...
+  const int nitems = mytiles * npass;
+  const int npk = sgpr(9 * g.cpp);                                 // K-steps per item
+  const long long nsteps = (long long)nitems * npk;                // K-steps of this block
 
-  if (tid < 128) {
-    const int nt = tid >> 4, f = tid & 15;
-    const int Rs = R0 + nt * g.NR + f / g.NC, w = c0 + f % g.NC;
-    const int n = Rs / H1, h = Rs - n * H1;
-    long long off = -1;
-    if (Rs < g.S && h < a.Hs && w < a.Ws) off = (((long long)n * a.Hs + h) * a.Ws + w) * a.Co;
-    row_dst[tid] = off;
-  }
+  unsigned long long t_begin = 0, t_w = 0, t_b = 0, t_e = 0, tq = 0;
+  auto now = [&]() -> unsigned long long {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+  };
+  if (STAMP) t_begin = now();
 
-  // ---- patch pieces of this wave: piece pg covers patch pixels 8*pg .. 8*pg+7 (one 1-KiB LDS-DMA instruction per chunk)
-  unsigned poff[MAXPG];
-  unsigned pval = 0;
+  // ---- tile geometry
+  auto tile_origin = [&](int T, int& R0, int& c0, int& co0) {
+    const int tc = T % a.tilesC, tp = T / a.tilesC;
+    const int tcol = tp % g.tilesW, trow = tp / g.tilesW;
+    R0 = trow * g.TH; c0 = tcol * g.TW; co0 = tc * BNC;
+  };
+  // rin[par][pr] for the tile whose first stacked row is R0 (patch row pr <-> stacked row R0 + pr - 1)
+  auto make_rin = [&](int par, int R0) {
+    if (lane < PH) {
+      const int Rs = R0 + lane - 1;
+      const int n = Rs / H1, h = Rs - n * H1;
+      rin[par * 40 + lane] = (Rs >= 0 && Rs < g.S && h < a.Hs) ? (n * a.Hs + h) * a.Ws : -1;
+    }
+  };
+
+  // ---- patch pieces (waves 4-7): piece pg = (wave - 4) + 4 j covers patch pixels 8 pg .. 8 pg + 7 of a chunk
+  unsigned pgeo[MAXPG];                            // pr | pc << 8 | usable << 16 (fixed for the whole launch)
 #pragma unroll
   for (int j = 0; j < MAXPG; ++j) {
-    const int pg = wave + j * NW;
+    const int pg = (wave & 3) + 4 * j;
     const int pp = pg * 8 + (lane >> 3);
     const int pr = pp / g.PW, pc = pp - pr * g.PW;
-    const int Rs = R0 + pr - 1, cin = c0 + pc - 1;
-    const int n = Rs / H1, h = Rs - n * H1;
-    const bool v = pg < g.PP8 && pp < g.PP && Rs >= 0 && Rs < g.S && h < a.Hs && (unsigned)cin < (unsigned)a.Ws;
-    poff[j] = v ? (unsigned)(((((long long)n * a.Hs + h) * a.Ws + cin) * a.Ci) * 2) + (unsigned)(((lane & 7) ^ (pp & 7)) << 4) : 0u;
-    if (v) pval |= 1u << j;
+    pgeo[j] = (unsigned)pr | ((unsigned)pc << 8) | ((pg * 1024 < pchunk && pp < g.PP) ? 0x10000u : 0u);
   }
+  const unsigned pswz = (unsigned)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);
   const char* xbase = (const char*)a.src;
   const char* wbase = (const char*)a.wpk;
   const void* zero = (const void*)g_zero_page;
-  auto issue_patch = [&](int pass) {
-    for (int c = 0; c < g.cpp; ++c) {
-      const unsigned coff = (unsigned)((pass * g.cpp + c) * 128);
+  // issue the patch of (tile origin R0/c0 via rin[par], pass) into patch buffer `buf`
+  auto issue_patch = [&](int par, int c0, int pass, int buf) {
+    unsigned poff[MAXPG];
+    unsigned pval = 0;
+#pragma unroll
+    for (int j = 0; j < MAXPG; ++j) {
+      const int pr = (int)(pgeo[j] & 0xff), pc = (int)((pgeo[j] >> 8) & 0xff);
+      const int base = rin[par * 40 + pr], cin = c0 + pc - 1;
+      const bool v = (pgeo[j] & 0x10000u) && base >= 0 && (unsigned)cin < (unsigned)a.Ws;
+      poff[j] = v ? (unsigned)(((long long)(base + cin) * a.Ci) * 2) + pswz : 0u;
+      if (v) pval |= 1u << j;
+    }
+    unsigned char* pb = pbuf + (size_t)buf * PB;
+    for (int c = 0; c < cpp; ++c) {
+      const unsigned coff = (unsigned)((pass * cpp + c) * 128);
 #pragma unroll
       for (int j = 0; j < MAXPG; ++j) {
-        const int pg = wave + j * NW;
-        if (pg < g.PP8) {
+        const int pg = (wave & 3) + 4 * j;
+        if (pg * 1024 < pchunk) {
           const void* s = ((pval >> j) & 1u) ? (const void*)(xbase + (size_t)poff[j] + coff) : zero;
-          glds16(s, patch + ((size_t)c * g.PP8 + pg) * 1024);
+          glds16(s, pb + (size_t)c * pchunk + pg * 1024);
         }
       }
     }
   };
 
-  // ---- weight ring: thread -> slot (tid & 7) of rows (tid >> 3) + RPR i, source chunk kc = slot ^ (row & 7)
-  const int rlo = tid >> 3;
-  unsigned woff[WCH];
+  // ---- weight ring (waves 0-3): thread -> slot (ltid & 7) of rows (ltid >> 3) + 32 i, source chunk kc = slot ^ (row & 7)
+  const int ltid = tid & 255, rlo = ltid >> 3;
+  unsigned wrow[WCH];
 #pragma unroll
-  for (int i = 0; i < WCH; ++i)
-    woff[i] = (unsigned)(((long long)(co0 + rlo + RPR * i) * a.K_pad + (((tid & 7) ^ (rlo & 7)) * 8)) * 2);
-  const int nk = 9 * g.nch, npk = 9 * g.cpp;     // K-steps in total / per pass
-  // issue cursor (runs NST-1 steps ahead of the compute cursor): pass, tap, chunk -> K offset (tap*Ci + chunk*64) * 2 bytes
-  int ip = 0, it = 0, ic = 0;
-  auto issue_w = [&](int slot) {
-    const unsigned kb = (unsigned)((it * a.Ci + (ip * g.cpp + ic) * 64) * 2);
-    unsigned char* wb = smem + slot * STAGE + wave * 1024;
+  for (int i = 0; i < WCH; ++i) wrow[i] = (unsigned)(((long long)(rlo + 32 * i) * a.K_pad + (((ltid & 7) ^ (rlo & 7)) * 8)) * 2);
+  const int tapb = sgpr(a.Ci * 2), passb = sgpr(g.cpp * 128);
+  const unsigned tileb = (unsigned)((long long)BNC * a.K_pad * 2);      // bytes of one 128-row weight tile
+  // issue cursor: runs NST-1 K-steps ahead of the compute cursor, across items and tiles
+  int i_t = 0, i_tile = lb, it = 0, ic = 0, i_pass = 0;
+  unsigned ikb = 0, ipb = 0, iwt = (unsigned)(lb % a.tilesC) * tileb;
+  long long issued = 0;                             // K-steps issued so far
+  int islot = 0;
+  auto issue_w = [&]() {
+    if (ringw) {
+      unsigned char* wb = smem + islot * STAGE + (wave & 3) * 1024;
+      const unsigned kb = ikb + ipb + iwt;
 #pragma unroll
-    for (int i = 0; i < WCH; ++i) glds16(wbase + woff[i] + kb, wb + i * (RPR * ROWB));
-    if (++ic == g.cpp) { ic = 0; if (++it == 9) { it = 0; ++ip; } }
+      for (int i = 0; i < WCH; ++i) glds16(wbase + wrow[i] + kb, wb + i * (32 * ROWB));
+    }
+    if (++islot == NST) islot = 0;
+    ++issued;
+    ikb += 128;
+    if (++ic == cpp) {
+      ic = 0;
+      ikb += (unsigned)(tapb - passb);
+      if (++it == 9) {
+        it = 0; ikb = 0; ipb += (unsigned)passb;
+        if (++i_pass == npass) {
+          i_pass = 0; ipb = 0;
+          ++i_t; i_tile += nblocks;
+          iwt = (unsigned)(i_tile % a.tilesC) * tileb;
+        }
+      }
+    }
   };
 
-  Epi epi;
-  epi.prefetch(a, row_dst, co0, tid);            // contains the __syncthreads that publishes row_dst
-
-  issue_patch(0);
-#pragma unroll
-  for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) issue_w(s);
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---- fragments
   const int fr = lane & 15, fq = lane >> 4;
   int wro[MT], xpix[NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) wro[m] = lds_off((wc * MT + m) * 16 + fr, fq);
 #pragma unroll
   for (int n = 0; n < NT; ++n) xpix[n] = ((wp * NT + n) * g.NR + fr / g.NC) * g.PW + fr % g.NC;
+  const int q_r = ((tid >> 4) & 7) * g.NR + (tid & 15) / g.NC, q_c = (tid & 15) % g.NC;   // epilogue pixel of tid < 128
 
-  int ks = 0;
-  for (int pass = 0; pass < g.npass; ++pass) {
-    if (pass > 0) {
-      // every wave has left the previous pass's patch (trailing barrier of its last K-step): reload, then wait for
-      // everything (the ring stages issued earlier are older in the counter and have landed as well)
-      issue_patch(pass);
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
+  bf16x8 wfA[2][MT] = {}, xfA[2][NT] = {}, wfB[2][MT] = {}, xfB[2][NT] = {};
+  int rtw = 0, rc = 0, rslot = 0, rtoff = 0, rpb = 0, rbuf = 0, rkp = 0;   // read cursor (one K-step ahead of the MFMAs)
+  const unsigned ring_a = lds_addr(smem), patch_a = lds_addr(pbuf);
+  auto reads = [&](bf16x8 (&wf)[2][MT], bf16x8 (&xf)[2][NT]) {
+    const unsigned sb = ring_a + (unsigned)(rslot * STAGE);
+    const unsigned pb = patch_a + (unsigned)(rbuf * PB + rpb);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int pp = xpix[n] + rtoff;
+      const unsigned xr = pb + (unsigned)(pp * ROWB + ((fq ^ (pp & 7)) << 4));
+      xf[0][n] = *(const __attribute__((address_space(3))) bf16x8*)(size_t)xr;
+      xf[1][n] = *(const __attribute__((address_space(3))) bf16x8*)(size_t)(xr ^ 64u);
     }
-    int tap = 0, c = 0;
-    for (int kp = 0; kp < npk; ++kp, ++ks) {
-      const int pending = min(NST - 2, nk - 1 - ks);
-      if (NST >= 4 && pending >= 2) wait_vmcnt<2 * WCH>();
-      else if (NST >= 3 && pending >= 1) wait_vmcnt<WCH>();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      wf[0][m] = *(const __attribute__((address_space(3))) bf16x8*)(size_t)(sb + (unsigned)wro[m]);
+      wf[1][m] = *(const __attribute__((address_space(3))) bf16x8*)(size_t)(sb + (unsigned)(wro[m] ^ 64));
+    }
+    if (++rslot == NST) rslot = 0;
+    rpb += pchunk;
+    if (++rc == cpp) {
+      rc = 0; rpb = 0;
+      ++rtoff;
+      if (++rtw == 3) { rtw = 0; rtoff += PW - 3; }
+    }
+    if (++rkp == npk) { rkp = 0; rtw = 0; rtoff = 0; rbuf ^= 1; }      // next item: other patch buffer, tap (0,0)
+  };
+  f32x4 acc[MT][NT];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto mfmas = [&](bf16x8 (&wf)[2][MT], bf16x8 (&xf)[2][NT]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][m], xf[kk][n], acc[m][n], 0, 0, 0);
+  };
+  // ring stage of K-step `need` must have landed (ring waves; the others have nothing in that queue)
+  auto wait_stage = [&](long long need) {
+    if (ringw) {
+      const long long younger = issued - 1 - need;
+      if (younger >= 2) wait_vmcnt<2 * WCH>();
+      else if (younger == 1) wait_vmcnt<WCH>();
       else wait_vmcnt<0>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (ks + NST - 1 < nk) issue_w((ks + NST - 1) % NST);
-      const unsigned char* sb = smem + (ks % NST) * STAGE;
-      const int dh = (int)((a.tapcode >> (4 * tap)) & 3), dw = (int)((a.tapcode >> (4 * tap + 2)) & 3);   // already +1
-      const int toff = dh * g.PW + dw;
-      const unsigned char* pb = patch + (size_t)c * g.PP8 * 1024;
-      int xro[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int pp = xpix[n] + toff;
-        xro[n] = pp * ROWB + ((fq ^ (pp & 7)) << 4);
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 wf[MT], xf[NT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(sb + (wro[m] ^ (kk << 6)));
-#pragma unroll
-        for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(pb + (xro[n] ^ (kk << 6)));
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int n = 0; n < NT; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
-      }
-      if (++c == g.cpp) { c = 0; ++tap; }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                 // all fragment reads of this pass's patch are done
-  }
+  };
+
+  // ---- prologue: first tile's row table, its first patch, the first ring stages
+  int T = lb, R0, c0, co0;
+  tile_origin(T, R0, c0, co0);
+  if (wave == 4) make_rin(0, R0);
   __syncthreads();
-  epi.run(a, acc, smem, row_dst, co0, tid);
+  if (!ringw) issue_patch(0, c0, 0, 0);
+  for (int s = 0; s < NST - 1; ++s)
+    if (issued < nsteps) issue_w();
+  if (!ringw) wait_vmcnt<0>();
+  wait_stage(0);
+  __builtin_amdgcn_s_barrier();
+  reads(wfA, xfA);                                  // K-step 0 (set A)
+
+  long long ks = 0;                                 // K-steps computed
+  int item = 0;
+  for (int t = 0; t < mytiles; ++t, T += nblocks) {
+    tile_origin(T, R0, c0, co0);
+    const int par = t & 1;
+    if (tid < 128) {
+      const int base = rin[par * 40 + q_r + 1];
+      row_dst[tid] = (base >= 0 && c0 + q_c < a.Ws) ? (long long)(base + c0 + q_c) * a.Co : -1;
+    }
+    zero_acc();
+    for (int pass = 0; pass < npass; ++pass, ++item) {
+      // ---- prefetch the patch of the next item into the other buffer
+      const bool last_pass = pass + 1 == npass;
+      const bool have_next = item + 1 < nitems;
+      if (have_next) {
+        int nR0 = R0, nc0 = c0, nco0 = co0;
+        if (last_pass) {
+          tile_origin(T + nblocks, nR0, nc0, nco0);
+          if (wave == 4) make_rin(par ^ 1, nR0);
+          __syncthreads();
+        }
+        if (!ringw) issue_patch(last_pass ? par ^ 1 : par, nc0, last_pass ? 0 : pass + 1, (item + 1) & 1);
+      }
+      // ---- the item's K-steps; step kp of the item: set A if kp even, else set B (npk may be odd: sets swap per item)
+#define MGD_PG2_STEP(cw, cx, nw_, nx_)                                                          \
+      {                                                                                         \
+        const bool more = ks + 1 < nsteps;                                                      \
+        if (STAMP) tq = now();                                                                  \
+        if (more) wait_stage(ks + 1);                                                           \
+        if (kp + 1 == npk && have_next && !ringw) wait_vmcnt<0>();   /* next patch has landed */ \
+        __builtin_amdgcn_s_waitcnt(0xC07F);          /* lgkmcnt(0), a wait hipcc sees */         \
+        if (STAMP) { unsigned long long t2 = now(); t_w += t2 - tq; tq = t2; }                  \
+        __builtin_amdgcn_s_barrier();                                                           \
+        if (STAMP) t_b += now() - tq;                                                           \
+        if (issued < nsteps) issue_w();                                                         \
+        if (more) reads(nw_, nx_);                                                              \
+        mfmas(cw, cx);                                                                          \
+        ++ks;                                                                                   \
+      }
+      const bool startA = (((long long)item * npk) & 1) == 0;
+      int kp = 0;
+      if (!startA) { MGD_PG2_STEP(wfB, xfB, wfA, xfA) ++kp; }
+      while (kp + 2 <= npk) {
+        MGD_PG2_STEP(wfA, xfA, wfB, xfB)
+        ++kp;
+        MGD_PG2_STEP(wfB, xfB, wfA, xfA)
+        ++kp;
+      }
+      if (kp < npk) { MGD_PG2_STEP(wfA, xfA, wfB, xfB) ++kp; }
+#undef MGD_PG2_STEP
+    }
+    // ---- epilogue of the tile; its LDS tile lives in the patch buffer the last pass has just left
+    if (STAMP) tq = now();
+    __syncthreads();
+    {
+      unsigned char* el = pbuf + (size_t)((item - 1) & 1) * PB;
+      Epi epi;
+      epi.prefetch(a, row_dst, co0, tid, false);
+      epi.run(a, acc, el, row_dst, co0, tid);
+    }
+    __syncthreads();
+    if (STAMP) t_e += now() - tq;
+  }
+  if (STAMP && a.stamps && lane == 0) {
+    const unsigned long long t_end = now();
+    atomicAdd(a.stamps + 0, 0ull); atomicAdd(a.stamps + 1, t_w); atomicAdd(a.stamps + 2, t_b);
+    atomicAdd(a.stamps + 3, (t_end - t_begin) - t_w - t_b - t_e); atomicAdd(a.stamps + 4, t_e);
+    atomicAdd(a.stamps + 5, (unsigned long long)mytiles);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2172,18 +2322,25 @@ int launch_gemm2(GemmArgs& a, hipStream_t st) {
 }
 
 
-template <int WP, int NST>
-int launch_pgemm(GemmArgs& a, const PgArgs& g, hipStream_t st) {
+template <int NST>
+int launch_pgemm2(GemmArgs& a, PgArgs g, hipStream_t st) {
   a.tilesC = a.Co_pad / 128;
   a.nblk = a.tilesC * g.tilesR * g.tilesW;
-  size_t lds = (size_t)NST * 128 * ROWB + (size_t)g.cpp * g.PP8 * 1024 + 128 * 8;
-  auto k = conv_pgemm_kernel<WP, NST>;
+  size_t lds = (size_t)NST * 128 * ROWB + 2 * (size_t)g.pbytes + 320 + 128 * 8;
+  auto k = conv_pgemm2_kernel<NST>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_pgemm2_kernel<NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(128 * WP), lds, st, a, g);
+  int grid = a.nblk < 256 ? a.nblk : 256;            // one resident block per CU
+  if (a.dbg & 2) {
+    (void)hipGetSymbolAddress((void**)&a.stamps, HIP_SYMBOL(g_stamps));
+    hipLaunchKernelGGL((conv_pgemm2_kernel<NST, true>), dim3(grid), dim3(512), lds, st, a, g);
+    return 0;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a, g);
   return 0;
 }
 
@@ -2209,7 +2366,8 @@ bool pgemm_geometry(const mgd_conv_desc* d, PgArgs* g) {
   g->nch = d->Ci / 64; g->cpp = g->nch < 4 ? g->nch : 4;
   if (g->nch % g->cpp) return false;
   g->npass = g->nch / g->cpp;
-  return g->PP8 <= 26;
+  g->pbytes = 0;
+  return g->PP8 <= 26 && g->TH + 2 <= 40 && (g->nch == 1 || g->nch % 2 == 0);
 }
 
 template <int WC, int WP, int MT, int NT, int NS>
@@ -2401,17 +2559,21 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
       return MGD_OK;
     }
   }
-  // resident-patch form for the 3x3 stride-1 layers with Ci >= 64 (forward and stride-1 data gradient)
+  // persistent resident-patch form for the 3x3 stride-1 layers with Ci >= 64 (forward and stride-1 data gradient):
+  // opt-in (MGD_PGEMM=2), slower than the forms below at batch 16
   {
     static int pgemm = -1;
-    if (pgemm < 0) { const char* e = getenv("MGD_PGEMM"); pgemm = e ? atoi(e) : 1; }
+    if (pgemm < 0) { const char* e = getenv("MGD_PGEMM"); pgemm = e ? atoi(e) : 0; }
     PgArgs g;
-    if (variant == 3 && pgemm && pgemm_geometry(d, &g)) {
-      const size_t patchb = (size_t)g.cpp * g.PP8 * 1024;
-      if (patchb + 2 * 16384 + 1024 <= 80 * 1024) launch_pgemm<2, 2>(a, g, st);          // two 4-wave blocks per CU
-      else if (patchb + 4 * 16384 + 1024 <= 160 * 1024) launch_pgemm<4, 4>(a, g, st);    // one 8-wave block per CU
-      else launch_pgemm<4, 3>(a, g, st);
-      MGD_CHECK_LAUNCH("conv_gather_gemm(resident patch)");
+    if (variant == 3 && pgemm == 2 && pgemm_geometry(d, &g)) {
+      // passes of <= 2 chunks, two patch buffers (each also large enough for the epilogue's LDS tile)
+      g.cpp = g.nch < 2 ? g.nch : 2;
+      g.npass = g.nch / g.cpp;
+      const int need = 128 * (128 * 2 + 16) + 8 * 2 * 128 * 4 + 1024;
+      g.pbytes = g.cpp * g.PP8 * 1024 > need ? g.cpp * g.PP8 * 1024 : need;
+      if ((size_t)4 * 16384 + 2 * (size_t)g.pbytes + 2048 <= 160 * 1024) launch_pgemm2<4>(a, g, st);
+      else launch_pgemm2<3>(a, g, st);
+      MGD_CHECK_LAUNCH("conv_gather_gemm(persistent resident patch)");
       return MGD_OK;
     }
   }

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Ablation timing of the persistent resident-patch kernel on one layer (MGD_DBG bits: 32 no epilogue, 64 no MFMA,
+128 no fragment reads, 256 no ring DMA, 512 no patch DMA).  usage: MGD_DBG=<bits> python tools/ablate_pg.py cin cout H"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multigriddet_amd import ops
+ci, co, h = (int(v) for v in sys.argv[1:4])
+dev = torch.device("cuda:0")
+x = torch.randn(16, h, h, ci, device=dev).to(torch.bfloat16)
+w = torch.randn(co, 9, ci, device=dev) * 0.05
+pk = ops.PackedConv(co, ci, 3, 1, dev); pk.refresh(w)
+y = torch.empty(16, h, h, co, dtype=torch.bfloat16, device=dev)
+for _ in range(3):
+    ops.conv_fwd(x, pk, out=y)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    ops.conv_fwd(x, pk, out=y)
+e1.record(); torch.cuda.synchronize()
+print(f"DBG={os.environ.get('MGD_DBG','0'):>4} {ci}->{co}@{h}: {e0.elapsed_time(e1)*1e3/20:.1f} us")
