@@ -375,6 +375,33 @@ int mgd_letterbox_u8(const uint8_t* src, int H, int W, float* dst, int Hd, int W
                      const int32_t* kx, const int32_t* bx, int ksx, const int32_t* ky, const int32_t* by, int ksy,
                      float fill, void* ws, size_t ws_bytes, void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Strict-parity fp32 execution (the reference's default numeric type: Keras float32 layers, models/layers.py:43-95).
+ * fp32 NHWC activations, fp32 OHWI weights [Co][k*k][Ci] (the master layout, no packing), fp32 accumulation; direct
+ * kernels, no attempt at speed - for end-to-end comparison of the 69-conv graph with the oracle under a tight bound
+ * (Network(precision="fp32")).  Geometry as Conv2D in the reference: 'same' for stride 1; stride 2 =
+ * ZeroPadding2D(((1,0),(1,0))) + 'valid' (models/backbones/darknet.py:33-34).
+ * dgrad: dx = (addend) + conv^T(dy); wgrad: dw += x (*) dy; bn_stats: stats[0..C) += sum y, stats[C..2C) += sum y^2 (feed
+ * mgd_bn_finalize with replicas = 1); bn_act_bwd: sums is a zeroed [2C] scratch; dgamma / dbeta are accumulated.
+ * ---------------------------------------------------------------------------------------------- */
+int mgd_conv2d_f32_fwd(const float* x, const float* w, float* y, const float* bias, int N, int H, int W, int Ci, int Co,
+                       int k, int s, void* stream);
+int mgd_conv2d_f32_dgrad(const float* dy, const float* w, float* dx, const float* addend, int N, int H, int W, int Ci,
+                         int Co, int k, int s, void* stream);
+int mgd_conv2d_f32_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Ci, int Co, int k, int s,
+                         void* stream);
+int mgd_bn_stats_f32(const float* y, int64_t P, int C, float* stats, void* stream);
+int mgd_bn_act_fwd_f32(const float* y, const float* scale, const float* shift, const float* residual, float* a, int64_t P,
+                       int C, float slope, void* stream);
+int mgd_bn_act_bwd_f32(const float* da, const float* y, const float* scale, const float* shift, const float* save_mean,
+                       const float* save_invstd, float* sums, float* dgamma, float* dbeta, float* dy, int64_t P, int C,
+                       float slope, int frozen, void* stream);
+int mgd_upsample_concat_fwd_f32(const float* u, const float* skip, float* out, int N, int h, int w, int Cu, int Cs,
+                                void* stream);
+int mgd_upsample_concat_bwd_f32(const float* dout, float* du, float* dskip, int N, int h, int w, int Cu, int Cs,
+                                void* stream);
+int mgd_bias_grad_f32(const float* dy, float* dbias, int64_t P, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,8 @@ EXPORTS = [
     "mgd_nms_workspace_size", "mgd_nms", "mgd_wbf_workspace_size", "mgd_wbf", "mgd_iou_matrix", "mgd_eval_match", "mgd_mosaic", "mgd_gridmask", "mgd_mixup",
     "mgd_comm_unique_id", "mgd_comm_init", "mgd_comm_allreduce_bucket", "mgd_comm_destroy",
     "mgd_letterbox_workspace_size", "mgd_letterbox_u8",
+    "mgd_conv2d_f32_fwd", "mgd_conv2d_f32_dgrad", "mgd_conv2d_f32_wgrad", "mgd_bn_stats_f32", "mgd_bn_act_fwd_f32",
+    "mgd_bn_act_bwd_f32", "mgd_upsample_concat_fwd_f32", "mgd_upsample_concat_bwd_f32", "mgd_bias_grad_f32",
 ]
 
 

@@ -15,6 +15,7 @@ import torch
 
 from . import _lib as L
 from . import ops
+from . import ops32
 
 STAGES = ((64, 1), (128, 2), (256, 8), (512, 8), (1024, 4))
 BACKBONE_CONVS = 52
@@ -56,9 +57,18 @@ class Conv:
 
 
 class Network:
-    def __init__(self, num_classes=80, num_anchors=3, device="cuda:0", seed=0):
+    def __init__(self, num_classes=80, num_anchors=3, device="cuda:0", seed=0, precision="bf16"):
+        """precision: "bf16" (bf16 storage, fp32 accumulation on the matrix cores - the fast path) or "fp32" (every
+        activation, conv and BatchNorm in fp32 through the direct kernels of csrc/fp32ref.hip: the reference's default
+        numeric type, for strict end-to-end parity runs; slow by design)."""
         L.require_gpu()
         L.load()
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        self.precision = precision
+        self.fp32 = precision == "fp32"
+        self.O = ops32 if self.fp32 else ops          # the op set forward / backward call
+        self.act_dtype = torch.float32 if self.fp32 else torch.bfloat16
         self.device = torch.device(device)
         self.num_classes, self.num_anchors = num_classes, num_anchors
         self.out_ch = num_anchors + num_classes + 5
@@ -87,7 +97,7 @@ class Network:
         n_bn = sum(l.cout for l in self.layers if l.bn)
         self.moving = torch.zeros(2 * n_bn, dtype=torch.float32, device=dev)
         self.bnwork = torch.zeros(4 * n_bn, dtype=torch.float32, device=dev)          # scale, shift, mean, invstd
-        R = ops.STATS_REPLICAS
+        R = self.O.STATS_REPLICAS
         self.stats_all = torch.zeros(n_bn * (2 * R + 2 * (R + 1)), dtype=torch.float32, device=dev)
         bo, so = 0, 0
         for cv in self.layers:
@@ -111,19 +121,31 @@ class Network:
             if cv.role == "stem":       # forward and weight gradient read the fp32 master weights / image directly
                 cv.pk = None
                 cv.wpack = None
+            elif self.fp32:             # fp32 mode: no packed images, the kernels read the master weights
+                cv.pk = ops32.PackedConv(cv.cout, cv.cin, cv.k, cv.s)
+                cv.pk.refresh(cv.w)
+                cv.wpack = None
             else:
                 cv.pk = ops.PackedConv(cv.cout, cv.cin, cv.k, cv.s, dev, need_dgrad=True)
                 cv.wpack = cv.w
-        self._pack_all = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers if cv.pk is not None], dev)
-        self._pack_head = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers[BACKBONE_CONVS:]], dev)
+        if self.fp32:
+            class _NoPack:
+                def run(self):
+                    pass
+            self._pack_all = self._pack_head = _NoPack()
+            self._pack_seg = [_NoPack() for _ in EARLY_SPLITS + (0,)]
+        else:
+            self._pack_all = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers if cv.pk is not None], dev)
+            self._pack_head = ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers[BACKBONE_CONVS:]], dev)
         # early-optimiser segments: stage 5 of the backbone + the head, then stage 4, have their gradients long before
         # backward ends
         # segments [EARLY_SPLITS[k], EARLY_SPLITS[k-1]) from the end of the network, then the rest
-        self._pack_seg = []
-        hi = len(self.layers)
-        for lo in EARLY_SPLITS + (0,):
-            self._pack_seg.append(ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers[lo:hi] if cv.pk is not None], dev))
-            hi = lo
+        if not self.fp32:
+            self._pack_seg = []
+            hi = len(self.layers)
+            for lo in EARLY_SPLITS + (0,):
+                self._pack_seg.append(ops.PackBatch([(cv.pk, cv.wpack) for cv in self.layers[lo:hi] if cv.pk is not None], dev))
+                hi = lo
         self.training = True
         self.freeze_backbone = False
         self.freeze_all_but_pred = False
@@ -134,8 +156,8 @@ class Network:
         self.overlap_wgrad = True
         self.wg_stream = torch.cuda.Stream(device=dev)
         self.side_bias_grad = True      # bias gradients of the prediction convs ride on the weight-gradient side stream
-        self.fuse_stem_bn = True        # stem: BN backward applied inside the weight-gradient kernel (dy0 never written)
-        self.fuse_bn_reduce = True      # BN-backward reduction inside the dgrad epilogue that produces `da` (A/B: 0.9 ms/step faster)
+        self.fuse_stem_bn = not self.fp32        # stem: BN backward applied inside the weight-gradient kernel (dy0 never written)
+        self.fuse_bn_reduce = not self.fp32      # BN-backward reduction inside the dgrad epilogue that produces `da` (A/B: 0.9 ms/step faster)
         self._arenas = {}
         self.reset_parameters(seed)
 
@@ -213,7 +235,7 @@ class Network:
             return self._arenas[key]
         dev = self.device
         A = {"y": {}, "a": {}, "hw": {}}
-        bf = torch.bfloat16
+        bf = self.act_dtype
 
         def alloc(i, h, w):
             cv = self.layers[i]
@@ -253,7 +275,8 @@ class Network:
         self._arenas[key] = A
         return A
 
-    def _scratch(self, A, tag, shape, dtype=torch.bfloat16):
+    def _scratch(self, A, tag, shape, dtype=None):
+        dtype = self.act_dtype if dtype is None else dtype
         key = (tag, tuple(shape), dtype)
         t = A["scratch"].get(key)
         if t is None:
@@ -277,6 +300,8 @@ class Network:
         shift as bias, LeakyReLU and the residual add in the conv epilogue - one launch per DarknetConv2D_BN_Leaky
         (models/layers.py:88-95) instead of conv + BN/activation pass.  Opt-in (the unfolded path is the one the parity
         tests pin; folding rounds the scaled weights to bf16 instead of rounding y).  Call again after the weights change."""
+        if on and self.fp32:
+            raise RuntimeError("fold_bn is a bf16 inference mode")
         if on and self.training:
             raise RuntimeError("fold_bn is an inference-only mode: set training = False first (a training forward through "
                                "folded convs would leave the raw conv outputs backward needs stale)")
@@ -312,14 +337,14 @@ class Network:
         tr = self._bn_training(cv)
         y = A["y"][i]
         if getattr(self, "folded", False) and not tr and cv.role != "stem":
-            return ops.conv_fwd(x, cv.pk, out=A["a"][i], bias=self._fold_shift[cv.idx], act_slope=ops.LEAKY_SLOPE,
+            return self.O.conv_fwd(x, cv.pk, out=A["a"][i], bias=self._fold_shift[cv.idx], act_slope=ops.LEAKY_SLOPE,
                                 addend=residual, wimg=self._fold_imgs[cv.idx])
         if cv.role == "stem":       # matrix-core stem straight from the fp32 image (no im2col image in the forward pass)
-            ops.stem_fwd(x, cv.w, out=y, stats=cv.stats if tr else None)
+            self.O.stem_fwd(x, cv.w, out=y, stats=cv.stats if tr else None)
         else:
-            ops.conv_fwd(x, cv.pk, out=y, stats=cv.stats if tr else None)
+            self.O.conv_fwd(x, cv.pk, out=y, stats=cv.stats if tr else None)
         P = y.numel() // cv.cout
-        return ops.bn_act_fwd_fused(cv.stats, float(P), cv.gamma, cv.beta, cv.mm, cv.mv, cv.scale, cv.shift,
+        return self.O.bn_act_fwd_fused(cv.stats, float(P), cv.gamma, cv.beta, cv.mm, cv.mv, cv.scale, cv.shift,
                                     cv.smean, cv.sinv, y, A["a"][i], residual=residual, training=tr)
 
     def forward(self, images):
@@ -351,11 +376,11 @@ class Network:
             xb = self._conv_bn_act(A, i + 2, x)
             a4 = self._conv_bn_act(A, i + 3, xb)
             pred = self.layers[i + 4]
-            outs.append(ops.conv_fwd(a4, pred.pk, out=A["y"][i + 4], bias=pred.bias, out_f32=True))
+            outs.append(self.O.conv_fwd(a4, pred.pk, out=A["y"][i + 4], bias=pred.bias, out_f32=True))
             i += 5
             if sc < 2:
                 a6 = self._conv_bn_act(A, i, xb)
-                x = ops.upsample_concat_fwd(a6, skips[sc], A["cat"][sc])
+                x = self.O.upsample_concat_fwd(a6, skips[sc], A["cat"][sc])
                 i += 1
         A["outs"] = outs
         self._last = A
@@ -377,7 +402,7 @@ class Network:
         y = A["y"][i]
         dy = self._scratch(A, ("dy", i) if self.overlap_wgrad else "dy", y.shape)
         frozen = not self._bn_training(cv)
-        ops.bn_act_bwd(da, y, cv.scale, cv.shift, cv.smean, cv.sinv, cv.sums, cv.dgamma, cv.dbeta, dy, frozen=frozen,
+        self.O.bn_act_bwd(da, y, cv.scale, cv.shift, cv.smean, cv.sinv, cv.sums, cv.dgamma, cv.dbeta, dy, frozen=frozen,
                        reduced=i in A["reduced"])
         return dy
 
@@ -385,17 +410,17 @@ class Network:
         """Weight gradient (and, for the biased prediction convs, the bias gradient: nothing on the dgrad/BN chain
         reads it, so it leaves the critical stream too)."""
         if not self.overlap_wgrad:
-            ops.conv_wgrad(x, dy, dw, k, s)
+            self.O.conv_wgrad(x, dy, dw, k, s)
             if dbias is not None:
-                ops.bias_grad(dy, dbias)
+                self.O.bias_grad(dy, dbias)
             return
         ev = torch.cuda.Event()
         ev.record()
         self.wg_stream.wait_event(ev)
         with torch.cuda.stream(self.wg_stream):
-            ops.conv_wgrad(x, dy, dw, k, s)
+            self.O.conv_wgrad(x, dy, dw, k, s)
             if dbias is not None:
-                ops.bias_grad(dy, dbias)
+                self.O.bias_grad(dy, dbias)
 
     def backward(self, douts, on_layer_done=None):
         """douts: three bf16 grads wrt the head outputs.  Accumulates into self.grads (zero it first).
@@ -429,50 +454,50 @@ class Network:
             if self.side_bias_grad:
                 self._wgrad(a4, dy5, pred.dw, 1, 1, dbias=pred.dbias)
             else:
-                ops.bias_grad(dy5, pred.dbias)
+                self.O.bias_grad(dy5, pred.dbias)
                 self._wgrad(a4, dy5, pred.dw, 1, 1)
             if on_layer_done and pred_only:
                 on_layer_done(c5)
             if pred_only:
                 continue
-            d_a4 = ops.conv_dgrad(dy5, pred.pk, hw[c4], out=self._scratch(A, "da_a", a4.shape), bnred=self._bnred(A, c4))
+            d_a4 = self.O.conv_dgrad(dy5, pred.pk, hw[c4], out=self._scratch(A, "da_a", a4.shape), bnred=self._bnred(A, c4))
             dy4 = self._bwd_bn(A, c4, d_a4)
             xb = acts[c3]
             self._wgrad(xb, dy4, Lr[c4].dw, 3, 1)
             # xb (= activation of c3) has a second consumer (the lateral conv c6) unless this is the last scale:
             # the launch that writes the FINAL d_xb carries c3's BN reduction
-            d_xb = ops.conv_dgrad(dy4, Lr[c4].pk, hw[c3], out=self._scratch(A, "da_b", xb.shape),
+            d_xb = self.O.conv_dgrad(dy4, Lr[c4].pk, hw[c3], out=self._scratch(A, "da_b", xb.shape),
                                   bnred=self._bnred(A, c3) if sc == 2 else None)
             if sc < 2:
                 c6 = base + 5
                 dy6 = self._bwd_bn(A, c6, d_up[sc])
                 self._wgrad(xb, dy6, Lr[c6].dw, 1, 1)
-                ops.conv_dgrad(dy6, Lr[c6].pk, hw[c3], out=d_xb, addend=d_xb, bnred=self._bnred(A, c3))
+                self.O.conv_dgrad(dy6, Lr[c6].pk, hw[c3], out=d_xb, addend=d_xb, bnred=self._bnred(A, c3))
             dy3 = self._bwd_bn(A, c3, d_xb)
             a2 = acts[c2]
             self._wgrad(a2, dy3, Lr[c3].dw, 1, 1)
-            d_a2 = ops.conv_dgrad(dy3, Lr[c3].pk, hw[c2], out=self._scratch(A, "da_a", a2.shape), bnred=self._bnred(A, c2))
+            d_a2 = self.O.conv_dgrad(dy3, Lr[c3].pk, hw[c2], out=self._scratch(A, "da_a", a2.shape), bnred=self._bnred(A, c2))
             dy2 = self._bwd_bn(A, c2, d_a2)
             a1 = acts[c1]
             self._wgrad(a1, dy2, Lr[c2].dw, 3, 1)
-            d_a1 = ops.conv_dgrad(dy2, Lr[c2].pk, hw[c1], out=self._scratch(A, "da_b", a1.shape), bnred=self._bnred(A, c1))
+            d_a1 = self.O.conv_dgrad(dy2, Lr[c2].pk, hw[c1], out=self._scratch(A, "da_b", a1.shape), bnred=self._bnred(A, c1))
             dy1 = self._bwd_bn(A, c1, d_a1)
             xin = A["cat"][sc - 1] if sc > 0 else acts[BACKBONE_CONVS - 1]
             self._wgrad(xin, dy1, Lr[c1].dw, 1, 1)
             if on_layer_done:
                 on_layer_done(c1)
             if sc > 0:
-                d_cat = ops.conv_dgrad(dy1, Lr[c1].pk, hw[c1], out=self._scratch(A, "dcat", xin.shape))
+                d_cat = self.O.conv_dgrad(dy1, Lr[c1].pk, hw[c1], out=self._scratch(A, "dcat", xin.shape))
                 lat = Lr[head0 + (sc - 1) * 6 + 5]
                 gh, gw = hw[lat.idx]
                 du = self._scratch(A, f"du{sc}", (B, gh, gw, lat.cout))
                 skip_c = xin.shape[-1] - lat.cout
                 dsk = self._scratch(A, f"dskip{sc}", (B, 2 * gh, 2 * gw, skip_c))
-                ops.upsample_concat_bwd(d_cat, du, dsk)
+                self.O.upsample_concat_bwd(d_cat, du, dsk)
                 d_skip[sc - 1] = dsk
                 d_up[sc - 1] = du
             elif not train_head_only:
-                g_f1 = ops.conv_dgrad(dy1, Lr[c1].pk, hw[c1], out=self._scratch(A, "g5", acts[BACKBONE_CONVS - 1].shape),
+                g_f1 = self.O.conv_dgrad(dy1, Lr[c1].pk, hw[c1], out=self._scratch(A, "g5", acts[BACKBONE_CONVS - 1].shape),
                                       bnred=self._bnred(A, BACKBONE_CONVS - 1))
         if pred_only or train_head_only:
             self._join_wgrad()
@@ -490,12 +515,12 @@ class Network:
                 dy2 = self._bwd_bn(A, l2, g)                     # residual branch: d a2 = g
                 a1 = acts[l1]
                 self._wgrad(a1, dy2, Lr[l2].dw, 3, 1)
-                d_a1 = ops.conv_dgrad(dy2, Lr[l2].pk, hw[l1], out=self._scratch(A, "da_a", a1.shape),
+                d_a1 = self.O.conv_dgrad(dy2, Lr[l2].pk, hw[l1], out=self._scratch(A, "da_a", a1.shape),
                                       bnred=self._bnred(A, l1))
                 dy1 = self._bwd_bn(A, l1, d_a1)
                 self._wgrad(x_in, dy1, Lr[l1].dw, 1, 1)
                 # g <- g + dgrad (in place); g is then the `da` of the layer that produced x_in (l1 - 1)
-                ops.conv_dgrad(dy1, Lr[l1].pk, hw[l1], out=g, addend=g, bnred=self._bnred(A, l1 - 1))
+                self.O.conv_dgrad(dy1, Lr[l1].pk, hw[l1], out=g, addend=g, bnred=self._bnred(A, l1 - 1))
                 if on_layer_done:
                     on_layer_done(l1)
                 i -= 2
@@ -504,7 +529,7 @@ class Network:
             dyd = self._bwd_bn(A, ld, g)
             if st == 0:
                 self._wgrad(x_prev, dyd, Lr[ld].dw, 3, 2)
-                g = ops.conv_dgrad(dyd, Lr[ld].pk, hw[0], out=self._scratch(A, "g0", x_prev.shape), bnred=self._bnred(A, 0))
+                g = self.O.conv_dgrad(dyd, Lr[ld].pk, hw[0], out=self._scratch(A, "g0", x_prev.shape), bnred=self._bnred(A, 0))
             else:
                 self._wgrad(x_prev, dyd, Lr[ld].dw, 3, 2)
                 add = None
@@ -512,7 +537,7 @@ class Network:
                     add = d_skip[0]      # f2 (stage-4 output) also fed the scale-2 concat
                 elif st == 3:
                     add = d_skip[1]      # f3 (stage-3 output) also fed the scale-3 concat
-                g = ops.conv_dgrad(dyd, Lr[ld].pk, hw[ld - 1], out=self._scratch(A, f"g{st}", x_prev.shape), addend=add,
+                g = self.O.conv_dgrad(dyd, Lr[ld].pk, hw[ld - 1], out=self._scratch(A, f"g{st}", x_prev.shape), addend=add,
                                    bnred=self._bnred(A, ld - 1))
             if on_layer_done:
                 on_layer_done(ld)
@@ -521,7 +546,7 @@ class Network:
         if self.fuse_stem_bn and 0 in A["reduced"] and self._bn_training(c0):
             # the sums are already there (fused into layer 1's input gradient): apply BN backward inside the weight
             # gradient, dy0 never touches HBM
-            ops.stem_wgrad_bn(A["image"], g, A["y"][0], c0.scale, c0.shift, c0.smean, c0.sinv, c0.sums, c0.dgamma,
+            self.O.stem_wgrad_bn(A["image"], g, A["y"][0], c0.scale, c0.shift, c0.smean, c0.sinv, c0.sums, c0.dgamma,
                               c0.dbeta, c0.dw)
         else:
             dy0 = self._bwd_bn(A, 0, g)
@@ -530,7 +555,7 @@ class Network:
             side = self.wg_stream if self.overlap_wgrad else torch.cuda.current_stream()
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                ops.stem_wgrad(A["image"], dy0, c0.dw)       # matrix cores, straight from the fp32 image
+                self.O.stem_wgrad(A["image"], dy0, c0.dw)       # matrix cores, straight from the fp32 image
         self._join_wgrad()
         if on_layer_done:
             on_layer_done(0)

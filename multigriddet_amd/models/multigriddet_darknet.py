@@ -61,9 +61,9 @@ class MultiGridDetModel:
     name = "multigriddet_darknet"
 
     def __init__(self, input_shape=(416, 416, 3), num_anchors_per_head=(3, 3, 3), num_classes=80, device="cuda:0",
-                 seed=0):
+                 seed=0, precision="bf16"):
         self.input_shape = tuple(input_shape)
-        self.net = Network(num_classes, int(num_anchors_per_head[0]), device, seed=seed)
+        self.net = Network(num_classes, int(num_anchors_per_head[0]), device, seed=seed, precision=precision)
         self.net.training = False
         names = _keras_names(self.net)
         self.layers = [_Layer(n[0], self, i) for i, n in enumerate(names)]
@@ -192,7 +192,7 @@ class MultiGridDetModel:
 def build_multigriddet_darknet(input_shape=(416, 416, 3), num_anchors_per_head=(3, 3, 3), num_classes=80,
                                weights_path=None, clear_session=False, **kwargs):
     model = MultiGridDetModel(input_shape, num_anchors_per_head, num_classes, device=kwargs.get("device", "cuda:0"),
-                              seed=kwargs.get("seed", 0))
+                              seed=kwargs.get("seed", 0), precision=kwargs.get("precision", "bf16"))
     if weights_path and (os.path.exists(weights_path) or os.path.exists(weights_path + ".npz")):
         model.load_weights(weights_path, backbone_only=True)
         print(f"Loaded backbone weights from {weights_path}")

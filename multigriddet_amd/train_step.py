@@ -66,7 +66,7 @@ class TrainStep:
             cfg = ops.make_loss_cfg(self.anchors, self.num_classes, (H, W), B, self._grids(H, W), **self.loss_kwargs)
             self._loss[key] = ops.LossRunner(cfg, self.net.device, class_weights=self.class_weights)
             F = 5 + len(self.anchors[0]) + self.num_classes
-            self._douts[key] = [torch.empty(B, g[0], g[1], F, dtype=torch.bfloat16, device=self.net.device)
+            self._douts[key] = [torch.empty(B, g[0], g[1], F, dtype=self.net.act_dtype, device=self.net.device)
                                 for g in self._grids(H, W)]
         return self._loss[key], self._douts[key]
 
@@ -144,7 +144,7 @@ class TrainStep:
         outs = net.forward(images)
         net.zero_grad()
         runner, douts = self._loss_runner(B, H, W)
-        comp = runner.run(y_true, outs, grad_bf16=douts)
+        comp = runner.run(y_true, outs, **({"grad_f32": douts} if net.fp32 else {"grad_bf16": douts}))
         if self.world > 1:
             rng_ = net.trainable_range()
             lo = rng_[0] if rng_ else 0

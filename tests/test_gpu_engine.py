@@ -165,6 +165,80 @@ def test_training_mode_forward_backward_vs_oracle(setup):
     assert min(cs[52:]) > 0.8 and float(np.median(cs)) > 0.7
 
 
+def test_fp32_precision_end_to_end_vs_oracle_strict():
+    """Network(precision="fp32"): the whole 69-conv graph in the reference's default numeric type (Keras float32,
+    models/layers.py:43-95) - forward with batch-statistic BatchNorm, MultiGridLoss, backward through every layer -
+    against the fp32 torch-CPU oracle with identical weights.  With bf16 storage this comparison needs cosine bounds
+    (test_training_mode_forward_backward_vs_oracle); in fp32 the bounds are tight: heads to 1e-3 relative L2, loss to
+    1e-4, every one of the 69 kernel gradients, every BatchNorm gamma/beta gradient and the bias gradients to cosine
+    0.999 and norm ratio 1 +- 1e-2 (float32 summation order is the only difference left; the first layers sit behind
+    ~130 layer applications of a random-init network, which amplifies even that: the stem reaches 0.99988)."""
+    from multigriddet_amd.engine import Network
+    from multigriddet_amd import ops
+    from oracle import model as om
+    from oracle.loss import MultiGridLossOracle
+    from oracle import targets as ot
+    net = Network(80, 3, "cuda:0", seed=0, precision="fp32")
+    params = om.init_params(seed=3)
+    rng = np.random.default_rng(4)
+    for p in params:
+        if "gamma" in p:
+            p["gamma"] = rng.uniform(0.7, 1.3, p["gamma"].shape).astype(np.float32)
+            p["beta"] = rng.normal(0, 0.1, p["beta"].shape).astype(np.float32)
+        else:
+            p["bias"] = rng.normal(0, 0.1, p["bias"].shape).astype(np.float32)
+    net.load_keras_style(params)
+    B, S = 4, 256
+    rng = np.random.default_rng(0)
+    img = rng.random((B, S, S, 3), dtype=np.float32)
+    tb = _boxes(rng, B, S)
+    yt = ot.tf_preprocess_true_boxes(tb, (S, S), coco_anchors(), 80)
+    tp = om.torch_params(params, requires_grad=True)
+    outs_ref = om.forward(torch.from_numpy(img), tp, training=True, emulate_bf16=False)
+    loss_ref = MultiGridLossOracle(coco_anchors(), 80, (S, S))([torch.from_numpy(y) for y in yt], outs_ref)
+    loss_ref.backward()
+    net.training = True
+    outs = net.forward(torch.from_numpy(img).cuda())
+    grids = [(S // 32,) * 2, (S // 16,) * 2, (S // 8,) * 2]
+    run = ops.LossRunner(ops.make_loss_cfg(coco_anchors(), 80, (S, S), B, grids), net.device)
+    douts = [torch.empty_like(o) for o in outs]
+    comp = run.run([torch.from_numpy(y).cuda() for y in yt], outs, grad_f32=douts)
+    net.zero_grad()
+    net.backward(douts)
+    torch.cuda.synchronize()
+    for l in range(3):
+        r = rel_l2(outs[l].cpu().numpy(), outs_ref[l].detach().numpy())
+        assert r < 1e-3, f"head {l} rel-L2 {r}"
+    assert abs(float(comp[7]) - float(loss_ref.detach())) < 1e-4 * abs(float(loss_ref.detach()))
+    g = net.grads.cpu().numpy()
+    worst = (1.0, -1)
+    for cv, p in zip(net.layers, tp):
+        gw = g[cv.off_w:cv.off_w + cv.cout * cv.T * cv.cin].reshape(cv.cout, cv.k, cv.k, cv.cin)
+        ref = p["kernel"].grad.numpy().transpose(3, 0, 1, 2)
+        c = cosine(gw, ref)
+        worst = min(worst, (c, cv.idx))
+        assert c > 0.999, f"layer {cv.idx} ({cv.role}) kernel-grad cosine {c}"
+        nr = np.linalg.norm(gw) / (np.linalg.norm(ref) + 1e-30)
+        assert abs(nr - 1.0) < 1e-2, f"layer {cv.idx} kernel-grad norm ratio {nr}"
+        if cv.bn:
+            assert cosine(g[cv.off_a:cv.off_a + cv.cout], p["gamma"].grad.numpy()) > 0.999, f"layer {cv.idx} dgamma"
+            assert cosine(g[cv.off_b:cv.off_b + cv.cout], p["beta"].grad.numpy()) > 0.999, f"layer {cv.idx} dbeta"
+        else:
+            assert cosine(g[cv.off_a:cv.off_a + cv.cout], p["bias"].grad.numpy()) > 0.9999
+    assert min(cosine(g[cv.off_w:cv.off_w + cv.cout * cv.T * cv.cin].reshape(cv.cout, cv.k, cv.k, cv.cin),
+                      p["kernel"].grad.numpy().transpose(3, 0, 1, 2)) for cv, p in list(zip(net.layers, tp))[52:]) > 0.9999
+    print("fp32 end to end: worst kernel-grad cosine", worst)
+    # moving statistics follow Keras' momentum update from the batch statistics (momentum 0.99)
+    n_bn = net.moving.numel() // 2
+    assert float(net.moving[:n_bn].abs().max()) > 0 and torch.isfinite(net.moving).all()
+    # one optimiser step in fp32 mode through TrainStep
+    from multigriddet_amd.train_step import TrainStep
+    ts = TrainStep(net, coco_anchors(), 80, (S, S), B, lr=1e-3)
+    l0 = float(ts.step(torch.from_numpy(img).cuda(), torch.from_numpy(tb).cuda())[7])
+    l1 = float(ts.step(torch.from_numpy(img).cuda(), torch.from_numpy(tb).cuda())[7])
+    assert np.isfinite([l0, l1]).all() and l1 < l0
+
+
 def test_inference_mode_and_frozen_backbone(setup):
     net, params = setup
     from oracle import model as om
