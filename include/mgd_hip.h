@@ -82,9 +82,17 @@ typedef struct mgd_conv_desc {
    * act_slope != 0 applies LeakyReLU(act_slope) to (acc + bias) before the optional `addend` (= the residual input),
    * i.e. the whole DarknetConv2D_BN_Leaky (+ Add) of models/layers.py:88-95 in one launch.  bf16 output only. */
   float act_slope;
+  /* optional: the same weights in MFMA-fragment order (mgd_frag_pack); enables the persistent resident-patch form of
+   * the 3x3 stride-1 gather-GEMM when the library runs with MGD_PGEMM=1 */
+  const void* wfrag;
 } mgd_conv_desc;
 
 int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream);
+/* Re-lays a packed 3x3 image [Co_pad][K_pad = 9*Ci] (Co_pad % 128 == 0, Ci % 64 == 0) out in MFMA-fragment order: per
+ * (channel tile of 128, or 256 when Co_pad % 256 == 0; pass of 64 or 128 input channels; K-step) one block
+ * [wave(4)][half][m(2)][kk(2)][lane(64)] x 16 B, so that a wave's A operand is coalesced 1-KiB loads.  The image is opaque:
+ * written here, read by mgd_conv_gather_gemm through mgd_conv_desc.wfrag.  frag has the size of packed. */
+int mgd_frag_pack(const void* packed, void* frag, int Co_pad, int K_pad, int Ci, void* stream);
 
 /* Stride-2 data gradient of a 3x3 conv with 32 input / 64 output channels (the first down-sampling layer,
  * models/backbones/darknet.py:33-34 with ZeroPadding2D(((1,0),(1,0))): all four output-parity classes in one launch,

@@ -66,6 +66,15 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
+// Workgroup barrier for data handed over through LDS only: waits for this wave's LDS operations, not for its global
+// loads / stores.  __syncthreads() also drains vmcnt: after an epilogue's store loop that is the full HBM write
+// acknowledgement latency (stamps: 16-19 thousand cycles per 128x128 tile, as long as an 18-step K-loop), during which the
+// block holds its CU slot for nothing.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
       }
     }
   }
-  __syncthreads();
+  lds_barrier();        // LDS tile published; no vmcnt wait (see lds_barrier)
   const int CPR = BNC * esz / 16;
   if (a.dst_f32) {
     for (int q = tid; q < BMP * CPR; q += NTHR) {
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
         wred[wave * 2 * BNC + BNC + lane * 8 + j] = r2[j];
       }
     }
-    __syncthreads();
+    lds_barrier();      // NOT __syncthreads(): that would wait for the tile's global stores to be acknowledged
     if (tid < 2 * BNC) {
       float t = 0.f;
 #pragma unroll
@@ -463,12 +472,19 @@ struct GemmEpilogue {
         ypre[it] = (bnred && ok) ? *(const uint4*)(a.bn_y + off + c) : make_uint4(0, 0, 0, 0);
         apre[it] = (addpre && ok) ? *(const uint4*)(a.addend + off + c) : make_uint4(0, 0, 0, 0);
       }
+    } else {
+      // defined on every path, HERE: left undefined, hipcc materialises the zeros at kernel entry and carries them (in
+      // scratch, in the persistent kernels) across the K-loop; their reloads in the store loop then wait vmcnt(0)
+#pragma unroll
+      for (int it = 0; it < EPC; ++it) ypre[it] = apre[it] = make_uint4(0, 0, 0, 0);
     }
   }
 
   // call after a __syncthreads() that follows the last LDS read of the K-loop.  DEFER: the per-channel sums stay in
   // this thread's registers (pr1/pr2) instead of being reduced and added to global memory - flush() does that once.
-  template <bool DEFER = false>
+  // LATE: fetch the HBM operands (prefetch()) only after the accumulators have gone to LDS - for kernels that run the
+  // epilogue with little register headroom and gain nothing from fetching earlier
+  template <bool DEFER = false, bool LATE = false>
   __device__ __forceinline__ void run(const GemmArgs& a, f32x4 (&acc)[MT][NT], unsigned char* smem,
                                       const long long* row_dst, int co0, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -503,7 +519,11 @@ struct GemmEpilogue {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
+    if (LATE) {
+      __builtin_amdgcn_sched_barrier(0);          // keep the fetches below the point where the accumulators die
+      prefetch(a, row_dst, co0, tid, false);
+    }
     const int CPR = BNC * esz / 16;
     if (a.dst_f32) {
       for (int q = tid; q < BMP * CPR; q += NTHR) {
@@ -519,14 +539,25 @@ struct GemmEpilogue {
     float r1[8], r2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) r1[j] = r2[j] = 0.f;
+    // all LDS reads of the pass are issued before the first store: one LDS round trip per tile instead of two per chunk
+    long long offs[EPC];
+    uint4 vals[EPC];
+#pragma unroll
+    for (int it = 0; it < EPC; ++it) offs[it] = row_dst[(tid + it * NTHR) / CPB];
 #pragma unroll
     for (int it = 0; it < EPC; ++it) {
       const int q = tid + it * NTHR;
       const int r = q / CPB, ch = q - r * CPB;
-      const long long off = row_dst[r];
+      vals[it] = *(const uint4*)(smem + r * EROW + ch * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < EPC; ++it) {
+      const int q = tid + it * NTHR;
+      const int r = q / CPB, ch = q - r * CPB;
+      const long long off = offs[it];
       const int c = co0 + ch * 8;
       if (off < 0 || c >= a.Co) continue;
-      uint4 v = *(const uint4*)(smem + r * EROW + ch * 16);
+      uint4 v = vals[it];
       if (addpre) {
         float f[8], g[8];
         unpack8(v, f);
@@ -586,7 +617,7 @@ struct GemmEpilogue {
           wred[wave * 2 * BNC + BNC + lane * 8 + j] = r2[j];
         }
       }
-      __syncthreads();
+      lds_barrier();    // NOT __syncthreads(): that would wait for the tile's global stores to be acknowledged
       if (tid < 2 * BNC) {
         float t = 0.f;
 #pragma unroll
@@ -760,15 +791,14 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // "Resident patch" form of the 3x3 stride-1 gather-GEMM (forward and stride-1 data gradient) for Ci >= 64 (opt-in:
-// MGD_PGEMM=2; measured slower than the gather-GEMMs above at batch 16).
+// MGD_PGEMM=1; at batch 16 within a few percent of the gather-GEMMs above either way).
 //
 // The gather-GEMMs above stream BOTH operands through LDS-DMA every K-step: 32 KB per 128 x 128 x 64 step, and a CU takes
 // in ~32 B/clk from L2 (MI355X_MICROARCH.md: 66-73 GB/s per CU), i.e. >= 1000 cycles of DMA against 512 cycles of MFMA.
 // A 3x3 conv re-reads every input pixel nine times; here the haloed input patch of the block's 128 output pixels is
-// staged in LDS ONCE (all channels of a pass, 64-channel chunks, same XOR-swizzled 128-byte rows as the ring) and the
-// nine taps read it at shifted pixel indices - the only per-K-step DMA left is the 16 KB weight tile, which runs through
-// an NST-deep ring with counted vmcnt.  Out-of-image pixels come from a zero page when the patch is loaded: no per-tap
-// masks, no zero fix-ups in the loop.
+// staged in LDS ONCE per pass (64-channel chunks, same XOR-swizzled 128-byte rows as the ring) and the nine taps read it
+// at shifted pixel indices.  Out-of-image pixels come from a zero page when the patch is loaded: no per-tap masks, no
+// zero fix-ups in the loop.
 //
 // Pixel tile: 8 MFMA n-tiles of 16 pixels, an n-tile being NR rows x NC columns (NC = 16 / 8 / 4 chosen so that the map
 // width wastes least), stacked vertically: TH = 8*NR rows x TW = NC columns.  Rows run over the whole batch in "stacked"
@@ -786,297 +816,272 @@ struct PgArgs {
 // keeps a wave-uniform value in an SGPR and opaque to the compiler: it can then neither be re-loaded from the kernel
 // argument segment inside the K-loop (a scalar load there forces s_waitcnt lgkmcnt(0) in front of the MFMAs and with it
 // the just-issued fragment reads of the NEXT step) nor folded back into a longer expression
-// keeps a wave-uniform value in an SGPR and opaque to the compiler: it can then neither be re-loaded from the kernel
-// argument segment inside the K-loop (a scalar load there forces s_waitcnt lgkmcnt(0) in front of the MFMAs and with it
-// the just-issued fragment reads of the NEXT step) nor folded back into a longer expression
-// ds_read_b128 the compiler does not see: it adds no s_waitcnt for it (hipcc waits lgkmcnt(0) in front of the MFMAs of the
-// CURRENT step once the reads of the NEXT step are in flight), so completion is waited for by hand (lgkmcnt(0) at the top of
-// the next half-iteration, then touch8() on every destination before its first consumer)
-__device__ __forceinline__ void lds_read16_asm(bf16x8& dst, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %1" : "+v"(dst) : "v"(addr));     // "+v": the set keeps its registers around the loop
-}
-__device__ __forceinline__ void touch8(bf16x8& v) { asm volatile("" : "+v"(v)); }
-
 __device__ __forceinline__ int sgpr(int v) {
   asm volatile("" : "+s"(v));
   return v;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent kernel.  A one-tile-per-block version spent more than half of a block's life in its prologue on the 76x76
-// layers (stamps): the patch (46 KB, first touch from HBM) has to land before the first MFMA and a CU runs one block at a
-// time.  Here a block stays resident and walks its tiles; a work item is one pass
-// of one tile (<= 2 chunks = 128 input channels, 18 K-steps) and the patch of item i+1 is prefetched into the other of two
-// patch buffers while item i computes.  Waves 0-3 stream the weight ring, waves 4-7 the patches, so each wave's vmcnt queue
-// holds one kind of LDS-DMA only (ring waves: counted waits per stage; patch waves: one wait before the barrier that ends
-// the item); all eight waves compute.  The weight ring and the one-step-ahead fragment reads run on across item and tile
-// boundaries; the epilogue of a tile borrows the patch buffer the tile has just left.
-template <int NST, bool STAMP = false>
-__global__ __launch_bounds__(512) void conv_pgemm2_kernel(GemmArgs a, PgArgs g) {
-  constexpr int WC = 2, WP = 4, MT = 4, NT = 2;
-  using Epi = GemmEpilogue<WC, WP, MT, NT>;
-  constexpr int BNC = 128, STAGE = BNC * ROWB, WCH = 4, MAXPG = 7;
+// Arguments of the persistent resident-patch kernel.  The weights come from a second packed image in MFMA-fragment order
+// (frag_pack_kernel): a wave's A operand is then plain, fully coalesced 16-byte global loads straight into registers, not
+// an LDS round trip.
+struct Pg3Args {
+  const bf16_t* wfrag;               // fragment-ordered weights
+  int NC, NR, TH, TW, PW, PP, PP8, PH;
+  int S, tilesW, tilesR, npass;
+  int pbytes;                        // bytes of one patch buffer (>= CPP * PP8 * 1024 and >= the epilogue's LDS tile)
+};
 
+// fragment-ordered image from the standard packed image [Co_pad][K_pad], K = tap*Ci + ci (3x3, K_pad = 9*Ci, Ci % 64 == 0).
+// block (cot, p, j = tap*cpp + c) of hv*1024 16-byte chunks: chunk (((w*hv + h)*2 + m)*2 + kk)*64 + lane
+//   <- packed[row = cot*128*hv + h*128 + w*32 + m*16 + (lane&15)][k = tap*Ci + (p*cpp + c)*64 + (kk*4 + (lane>>4))*8 .. +8]
+// hv = 1: 128-channel block tiles (pgemm3, pgemm4<.,1>); hv = 2: 256-channel block tiles (pgemm4<.,2>)
+__global__ void frag_pack_kernel(const uint4* __restrict__ packed, uint4* __restrict__ frag, int K_pad, int Ci, int cpp, int hv,
+                                 long long nchunk) {
+  const int npass = Ci / (64 * cpp);
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nchunk; q += (long long)gridDim.x * blockDim.x) {
+    int lane = (int)(q & 63);
+    long long r = q >> 6;
+    int kk = (int)(r & 1); r >>= 1;
+    int m = (int)(r & 1); r >>= 1;
+    int h = (int)(r % hv); r /= hv;
+    int w = (int)(r & 3); r >>= 2;
+    int j = (int)(r % (9 * cpp)); r /= 9 * cpp;
+    int p = (int)(r % npass);
+    int cot = (int)(r / npass);
+    int tap = j / cpp, c = j - tap * cpp;
+    int row = cot * 128 * hv + h * 128 + w * 32 + m * 16 + (lane & 15);
+    int k = tap * Ci + (p * cpp + c) * 64 + (kk * 4 + (lane >> 4)) * 8;
+    frag[q] = packed[((long long)row * K_pad + k) >> 3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resident-patch gather-GEMM, persistent, one wave per SIMD with the SIMD's whole 512-register file (MGD_PGEMM=1).
+// Third form of the idea; what the first two (deleted, numbers in DESIGN.md section 3) taught:
+//  * ring form (weights through an LDS-DMA ring, 8 waves in lock step, one barrier per K-step): its parts added up instead
+//    of overlapping - K-loop skeleton 39 us, LDS-DMA 10, fragment reads 20, MFMA 20, epilogue 20 of 115 us on 128->256 at
+//    76x76; every LDS-DMA instruction cost its wave ~100 issue cycles;
+//  * free-running form (fragment-ordered weights from global memory, a fifth wave filling the patch, 32-channel x 128-pixel
+//    wave tiles): 93-99 us.  A 32 x 128 wave tile reads 16 KiB of pixel fragments from LDS per K-step, four waves = 64 KiB
+//    against 512 cycles of MFMA, and five waves per CU cap every wave at 256 registers (spills; their reloads in the
+//    epilogue wait vmcnt(0) and serialise the tile's stores).
+// This form runs FOUR waves per CU and nothing else:
+//  * wave tile 64 channels x 128 pixels (HV = 2; 128 accumulator registers in AGPRs), block tile 256 x 128: per K-step 64
+//    MFMA = 1024 cycles against the same 64 KiB of LDS reads;
+//  * weights from the fragment-ordered image, 8 coalesced 16-byte loads per K-step and lane, two K-steps ahead;
+//  * the four waves fill the next patch buffer themselves (LDS-DMA, issued right after the barrier that opens an item);
+//    loads return in order, so hipcc's counted waits on the weight loads behind them also wait for the DMA - one exposed
+//    L2 round trip per item of 9*CPP K-steps, the price of not having a fifth wave;
+//  * each wave keeps its own copy of the patch-row table (rin), so filling needs no extra barrier; row_dst is double
+//    buffered by tile parity and written one tile ahead;
+//  * the epilogue runs per 128-channel half through the GemmEpilogue of the other forms, in the patch buffer just left.
+// HV = 1 (Co_pad % 256 != 0) keeps 32 x 128 wave tiles.  A wave owns channels h*128 + wave*32 + m*16 of the block tile.
+// Measured (DBG = 2 ablation build, 128->256 at 76x76, batch 16, 80 us whole): patch DMA + barriers alone 17 us, weight +
+// pixel fragment loads +17, MFMA +28 (= 16 cycles each at 1.95 GHz), epilogue +13 (30 when nothing else runs: the 47 MB
+// of output at 1.6 TB/s) - still a sum, one wave per SIMD overlaps little of its own instruction stream.
+template <int CPP, int HV, int DBG = 0>   // DBG: 0 product, 1 cycle stamps, 2 ablation switches
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_pgemm4_kernel(GemmArgs a, Pg3Args g) {
+  constexpr int MT = 2, NT = 8, BNC = 128 * HV, NSTEP = 9 * CPP, BLK = HV * 1024;
+  constexpr bool STAMP = DBG == 1, ABL = DBG == 2;
+  using Epi = GemmEpilogue<4, 1, MT, NT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int cpp = sgpr(g.cpp), PW = sgpr(g.PW), npass = sgpr(g.npass);
-  const int pchunk = sgpr(g.PP8 * 1024);
-  const int PB = sgpr(g.pbytes);                                  // >= cpp * pchunk and >= the epilogue's LDS tile
-  unsigned char* pbuf = smem + NST * STAGE;                       // two patch buffers of PB bytes
-  int* rin = (int*)(pbuf + 2 * (size_t)PB);                       // [2][40]: first pixel index of each patch row, or -1
-  long long* row_dst = (long long*)(rin + 80);
+  const int PB = g.pbytes;
+  unsigned char* pbuf = smem;                                      // two patch buffers
+  int* rin = (int*)(smem + 2 * (size_t)PB);                        // [4 waves][2][40]: first pixel of each patch row, or -1
+  long long* row_dst = (long long*)(rin + 320);                    // [2][128]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool ringw = wave < 4;
-  const int wc = wave / WP, wp = wave % WP;
-  const int H1 = a.Hs + 1, PH = g.TH + 2;
+  int* rinw = rin + wave * 80;
+  const int H1 = a.Hs + 1;
   const int ntiles = a.nblk, nblocks = gridDim.x;
-  const int lb = xcd_remap(blockIdx.x, nblocks);                   // neighbouring logical ids share an XCD (and its L2)
-  const int mytiles = (ntiles - lb + nblocks - 1) / nblocks;       // tiles lb, lb + nblocks, ...
+  const int lb = xcd_remap(blockIdx.x, nblocks);
+  const int mytiles = (ntiles - lb + nblocks - 1) / nblocks;
+  const int npass = g.npass;
   const int nitems = mytiles * npass;
-  const int npk = sgpr(9 * g.cpp);                                 // K-steps per item
-  const long long nsteps = (long long)nitems * npk;                // K-steps of this block
+  const int pchunk = g.PP8 * 1024;
 
-  unsigned long long t_begin = 0, t_w = 0, t_b = 0, t_e = 0, tq = 0;
+  auto tile_origin = [&](int T, int& R0, int& c0, int& co0) {
+    const int tc = T % a.tilesC, tp = T / a.tilesC;
+    const int tcol = tp % g.tilesW, trow = tp / g.tilesW;
+    R0 = trow * g.TH; c0 = tcol * g.TW; co0 = tc * BNC;
+  };
+  const int e_r = ((tid >> 4) & 7) * g.NR + (tid & 15) / g.NC, e_c = (tid & 15) % g.NC;   // epilogue pixel of tid < 128
+  // patch-row table of a tile (this wave's copy) and the tile's output rows (tid < 128 = waves 0 and 1, from their copies)
+  auto make_rows = [&](int par, int R0, int c0) {
+    if (lane < g.PH) {
+      const int Rs = R0 + lane - 1;
+      const int n = Rs / H1, h = Rs - n * H1;
+      rinw[par * 40 + lane] = (Rs >= 0 && Rs < g.S && h < a.Hs) ? (n * a.Hs + h) * a.Ws : -1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (tid < 128) {
+      const int base = rinw[par * 40 + e_r + 1];
+      row_dst[par * 128 + tid] = (base >= 0 && c0 + e_c < a.Ws) ? (long long)(base + c0 + e_c) * a.Co : -1;
+    }
+  };
+  // piece j covers patch pixels 8j .. 8j+7 of a chunk (one 1-KiB LDS-DMA instruction per 64-channel chunk); wave w issues
+  // pieces w, w+4, ...
+  const char* xbase = (const char*)a.src;
+  const void* zero = (const void*)g_zero_page;
+  const unsigned pswz = (unsigned)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+  auto issue_patch = [&](int par, int c0, int pass, int buf) {
+    unsigned char* pb = pbuf + (size_t)buf * PB;
+    for (int j = wave; j < g.PP8; j += 4) {
+      const int pix = j * 8 + (lane >> 3);
+      const int pr = pix / g.PW, pc = pix - pr * g.PW;
+      const int base = pr < g.PH ? rinw[par * 40 + pr] : -1, cin = c0 + pc - 1;
+      const bool v = base >= 0 && (unsigned)cin < (unsigned)a.Ws;
+      const size_t off = (size_t)(((long long)(base + cin) * a.Ci) * 2) + pswz + (unsigned)(pass * CPP * 128);
+#pragma unroll
+      for (int c = 0; c < CPP; ++c)
+        glds16(v ? (const void*)(xbase + off + c * 128) : zero, pb + (size_t)c * pchunk + (size_t)j * 1024);
+    }
+  };
+
+  unsigned long long t_begin = 0, t_e = 0, t_b = 0, tq = 0;
   auto now = [&]() -> unsigned long long {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
   };
   if (STAMP) t_begin = now();
-
-  // ---- tile geometry
-  auto tile_origin = [&](int T, int& R0, int& c0, int& co0) {
-    const int tc = T % a.tilesC, tp = T / a.tilesC;
-    const int tcol = tp % g.tilesW, trow = tp / g.tilesW;
-    R0 = trow * g.TH; c0 = tcol * g.TW; co0 = tc * BNC;
-  };
-  // rin[par][pr] for the tile whose first stacked row is R0 (patch row pr <-> stacked row R0 + pr - 1)
-  auto make_rin = [&](int par, int R0) {
-    if (lane < PH) {
-      const int Rs = R0 + lane - 1;
-      const int n = Rs / H1, h = Rs - n * H1;
-      rin[par * 40 + lane] = (Rs >= 0 && Rs < g.S && h < a.Hs) ? (n * a.Hs + h) * a.Ws : -1;
-    }
-  };
-
-  // ---- patch pieces (waves 4-7): piece pg = (wave - 4) + 4 j covers patch pixels 8 pg .. 8 pg + 7 of a chunk
-  unsigned pgeo[MAXPG];                            // pr | pc << 8 | usable << 16 (fixed for the whole launch)
-#pragma unroll
-  for (int j = 0; j < MAXPG; ++j) {
-    const int pg = (wave & 3) + 4 * j;
-    const int pp = pg * 8 + (lane >> 3);
-    const int pr = pp / g.PW, pc = pp - pr * g.PW;
-    pgeo[j] = (unsigned)pr | ((unsigned)pc << 8) | ((pg * 1024 < pchunk && pp < g.PP) ? 0x10000u : 0u);
-  }
-  const unsigned pswz = (unsigned)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);
-  const char* xbase = (const char*)a.src;
-  const char* wbase = (const char*)a.wpk;
-  const void* zero = (const void*)g_zero_page;
-  // issue the patch of (tile origin R0/c0 via rin[par], pass) into patch buffer `buf`
-  auto issue_patch = [&](int par, int c0, int pass, int buf) {
-    unsigned poff[MAXPG];
-    unsigned pval = 0;
-#pragma unroll
-    for (int j = 0; j < MAXPG; ++j) {
-      const int pr = (int)(pgeo[j] & 0xff), pc = (int)((pgeo[j] >> 8) & 0xff);
-      const int base = rin[par * 40 + pr], cin = c0 + pc - 1;
-      const bool v = (pgeo[j] & 0x10000u) && base >= 0 && (unsigned)cin < (unsigned)a.Ws;
-      poff[j] = v ? (unsigned)(((long long)(base + cin) * a.Ci) * 2) + pswz : 0u;
-      if (v) pval |= 1u << j;
-    }
-    unsigned char* pb = pbuf + (size_t)buf * PB;
-    for (int c = 0; c < cpp; ++c) {
-      const unsigned coff = (unsigned)((pass * cpp + c) * 128);
-#pragma unroll
-      for (int j = 0; j < MAXPG; ++j) {
-        const int pg = (wave & 3) + 4 * j;
-        if (pg * 1024 < pchunk) {
-          const void* s = ((pval >> j) & 1u) ? (const void*)(xbase + (size_t)poff[j] + coff) : zero;
-          glds16(s, pb + (size_t)c * pchunk + pg * 1024);
-        }
-      }
-    }
-  };
-
-  // ---- weight ring (waves 0-3): thread -> slot (ltid & 7) of rows (ltid >> 3) + 32 i, source chunk kc = slot ^ (row & 7)
-  const int ltid = tid & 255, rlo = ltid >> 3;
-  unsigned wrow[WCH];
-#pragma unroll
-  for (int i = 0; i < WCH; ++i) wrow[i] = (unsigned)(((long long)(rlo + 32 * i) * a.K_pad + (((ltid & 7) ^ (rlo & 7)) * 8)) * 2);
-  const int tapb = sgpr(a.Ci * 2), passb = sgpr(g.cpp * 128);
-  const unsigned tileb = (unsigned)((long long)BNC * a.K_pad * 2);      // bytes of one 128-row weight tile
-  // issue cursor: runs NST-1 K-steps ahead of the compute cursor, across items and tiles
-  int i_t = 0, i_tile = lb, it = 0, ic = 0, i_pass = 0;
-  unsigned ikb = 0, ipb = 0, iwt = (unsigned)(lb % a.tilesC) * tileb;
-  long long issued = 0;                             // K-steps issued so far
-  int islot = 0;
-  auto issue_w = [&]() {
-    if (ringw) {
-      unsigned char* wb = smem + islot * STAGE + (wave & 3) * 1024;
-      const unsigned kb = ikb + ipb + iwt;
-#pragma unroll
-      for (int i = 0; i < WCH; ++i) glds16(wbase + wrow[i] + kb, wb + i * (32 * ROWB));
-    }
-    if (++islot == NST) islot = 0;
-    ++issued;
-    ikb += 128;
-    if (++ic == cpp) {
-      ic = 0;
-      ikb += (unsigned)(tapb - passb);
-      if (++it == 9) {
-        it = 0; ikb = 0; ipb += (unsigned)passb;
-        if (++i_pass == npass) {
-          i_pass = 0; ipb = 0;
-          ++i_t; i_tile += nblocks;
-          iwt = (unsigned)(i_tile % a.tilesC) * tileb;
-        }
-      }
-    }
-  };
-
-  // ---- fragments
   const int fr = lane & 15, fq = lane >> 4;
-  int wro[MT], xpix[NT];
+  int xpix[NT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) wro[m] = lds_off((wc * MT + m) * 16 + fr, fq);
-#pragma unroll
-  for (int n = 0; n < NT; ++n) xpix[n] = ((wp * NT + n) * g.NR + fr / g.NC) * g.PW + fr % g.NC;
-  const int q_r = ((tid >> 4) & 7) * g.NR + (tid & 15) / g.NC, q_c = (tid & 15) % g.NC;   // epilogue pixel of tid < 128
+  for (int n = 0; n < NT; ++n) xpix[n] = (n * g.NR + fr / g.NC) * g.PW + fr % g.NC;
+  const int PW = g.PW;
+  const unsigned pa = lds_addr(pbuf);
+  // block (cot, p, j) of the fragment image starts at chunk ((cot*npass + p)*NSTEP + j) * BLK; this wave: + wave*HV*256
+  const uint4* wlane = (const uint4*)g.wfrag + (size_t)wave * (HV * 256) + lane;
 
-  bf16x8 wfA[2][MT] = {}, xfA[2][NT] = {}, wfB[2][MT] = {}, xfB[2][NT] = {};
-  int rtw = 0, rc = 0, rslot = 0, rtoff = 0, rpb = 0, rbuf = 0, rkp = 0;   // read cursor (one K-step ahead of the MFMAs)
-  const unsigned ring_a = lds_addr(smem), patch_a = lds_addr(pbuf);
-  auto reads = [&](bf16x8 (&wf)[2][MT], bf16x8 (&xf)[2][NT]) {
-    const unsigned sb = ring_a + (unsigned)(rslot * STAGE);
-    const unsigned pb = patch_a + (unsigned)(rbuf * PB + rpb);
+  // ablation switches of the DBG = 2 build only (MGD_DBG bits: 32 no epilogue, 64 no MFMA, 128 no pixel-fragment reads,
+  // 256 no weight-fragment loads); constant false in the product build
+  const bool abl_e = ABL && (a.dbg & 32), abl_m = ABL && (a.dbg & 64), abl_b = ABL && (a.dbg & 128),
+             abl_a = ABL && (a.dbg & 256);
+  f32x4 acc[HV][MT][NT];
+  bf16x8 a0[HV][MT][2], a1[HV][MT][2], a2[HV][MT][2], bX[NT], bY[NT];   // A: three sets, two K-steps ahead
+  auto load_a = [&](bf16x8 (&af)[HV][MT][2], const uint4* wk) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int pp = xpix[n] + rtoff;
-      const unsigned xr = pb + (unsigned)(pp * ROWB + ((fq ^ (pp & 7)) << 4));
-      xf[0][n] = *(const __attribute__((address_space(3))) bf16x8*)(size_t)xr;
-      xf[1][n] = *(const __attribute__((address_space(3))) bf16x8*)(size_t)(xr ^ 64u);
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      wf[0][m] = *(const __attribute__((address_space(3))) bf16x8*)(size_t)(sb + (unsigned)wro[m]);
-      wf[1][m] = *(const __attribute__((address_space(3))) bf16x8*)(size_t)(sb + (unsigned)(wro[m] ^ 64));
-    }
-    if (++rslot == NST) rslot = 0;
-    rpb += pchunk;
-    if (++rc == cpp) {
-      rc = 0; rpb = 0;
-      ++rtoff;
-      if (++rtw == 3) { rtw = 0; rtoff += PW - 3; }
-    }
-    if (++rkp == npk) { rkp = 0; rtw = 0; rtoff = 0; rbuf ^= 1; }      // next item: other patch buffer, tap (0,0)
-  };
-  f32x4 acc[MT][NT];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  auto mfmas = [&](bf16x8 (&wf)[2][MT], bf16x8 (&xf)[2][NT]) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int h = 0; h < HV; ++h)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][m], xf[kk][n], acc[m][n], 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk) af[h][m][kk] = __builtin_bit_cast(bf16x8, wk[((h * 2 + m) * 2 + kk) * 64]);
   };
-  // ring stage of K-step `need` must have landed (ring waves; the others have nothing in that queue)
-  auto wait_stage = [&](long long need) {
-    if (ringw) {
-      const long long younger = issued - 1 - need;
-      if (younger >= 2) wait_vmcnt<2 * WCH>();
-      else if (younger == 1) wait_vmcnt<WCH>();
-      else wait_vmcnt<0>();
+  auto load_b = [&](bf16x8 (&bf_)[NT], unsigned pb, int toff, unsigned kkx) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int pp = xpix[n] + toff;
+      const unsigned xr = pb + (unsigned)(pp * ROWB + ((fq ^ (pp & 7)) << 4));
+      bf_[n] = *(const __attribute__((address_space(3))) bf16x8*)(size_t)(xr ^ kkx);
     }
   };
+  auto mfmas_kk = [&](bf16x8 (&af)[HV][MT][2], bf16x8 (&bf_)[NT], int kk) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int h = 0; h < HV; ++h)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[h][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[h][m][kk], bf_[n], acc[h][m][n], 0, 0, 0);
+  };
 
-  // ---- prologue: first tile's row table, its first patch, the first ring stages
   int T = lb, R0, c0, co0;
   tile_origin(T, R0, c0, co0);
-  if (wave == 4) make_rin(0, R0);
-  __syncthreads();
-  if (!ringw) issue_patch(0, c0, 0, 0);
-  for (int s = 0; s < NST - 1; ++s)
-    if (issued < nsteps) issue_w();
-  if (!ringw) wait_vmcnt<0>();
-  wait_stage(0);
-  __builtin_amdgcn_s_barrier();
-  reads(wfA, xfA);                                  // K-step 0 (set A)
-
-  long long ks = 0;                                 // K-steps computed
+  make_rows(0, R0, c0);
+  issue_patch(0, c0, 0, 0);
+  wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                     // patch of item 0 and row_dst[0] are published
   int item = 0;
+  const uint4* wk = wlane;
   for (int t = 0; t < mytiles; ++t, T += nblocks) {
     tile_origin(T, R0, c0, co0);
     const int par = t & 1;
-    if (tid < 128) {
-      const int base = rin[par * 40 + q_r + 1];
-      row_dst[tid] = (base >= 0 && c0 + q_c < a.Ws) ? (long long)(base + c0 + q_c) * a.Co : -1;
+    int nR0 = 0, nc0 = 0, nco0 = 0;
+    if (t + 1 < mytiles) {                           // rows of the NEXT tile: read one tile (>= one barrier) later
+      tile_origin(T + nblocks, nR0, nc0, nco0);
+      make_rows(par ^ 1, nR0, nc0);
     }
-    zero_acc();
+    wk = wlane + (size_t)((T % a.tilesC) * npass) * NSTEP * BLK;
+    load_a(a0, wk);                                  // steps 0 and 1 of the tile
+    load_a(a1, wk + BLK);
+    load_b(bX, pa + (unsigned)((item & 1) * PB), 0, 0u);
+#pragma unroll
+    for (int h = 0; h < HV; ++h)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[h][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int pass = 0; pass < npass; ++pass, ++item) {
-      // ---- prefetch the patch of the next item into the other buffer
-      const bool last_pass = pass + 1 == npass;
+      const unsigned pb = pa + (unsigned)((item & 1) * PB);
+      const unsigned pbn = pa + (unsigned)(((item + 1) & 1) * PB);
+      const bool more_passes = pass + 1 < npass;
       const bool have_next = item + 1 < nitems;
+      // the other buffer is free (end-of-item barrier, or the barrier that closed the previous tile's epilogue): fill it
       if (have_next) {
-        int nR0 = R0, nc0 = c0, nco0 = co0;
-        if (last_pass) {
-          tile_origin(T + nblocks, nR0, nc0, nco0);
-          if (wave == 4) make_rin(par ^ 1, nR0);
-          __syncthreads();
-        }
-        if (!ringw) issue_patch(last_pass ? par ^ 1 : par, nc0, last_pass ? 0 : pass + 1, (item + 1) & 1);
+        if (more_passes) issue_patch(par, c0, pass + 1, (item + 1) & 1);
+        else issue_patch(par ^ 1, nc0, 0, (item + 1) & 1);
       }
-      // ---- the item's K-steps; step kp of the item: set A if kp even, else set B (npk may be odd: sets swap per item)
-#define MGD_PG2_STEP(cw, cx, nw_, nx_)                                                          \
-      {                                                                                         \
-        const bool more = ks + 1 < nsteps;                                                      \
-        if (STAMP) tq = now();                                                                  \
-        if (more) wait_stage(ks + 1);                                                           \
-        if (kp + 1 == npk && have_next && !ringw) wait_vmcnt<0>();   /* next patch has landed */ \
-        __builtin_amdgcn_s_waitcnt(0xC07F);          /* lgkmcnt(0), a wait hipcc sees */         \
-        if (STAMP) { unsigned long long t2 = now(); t_w += t2 - tq; tq = t2; }                  \
-        __builtin_amdgcn_s_barrier();                                                           \
-        if (STAMP) t_b += now() - tq;                                                           \
-        if (issued < nsteps) issue_w();                                                         \
-        if (more) reads(nw_, nx_);                                                              \
-        mfmas(cw, cx);                                                                          \
-        ++ks;                                                                                   \
+      const uint4* wnext = wk + NSTEP * BLK;
+#define MGD_PG4_STEP(ca, na2, J)                                                                   \
+      {                                                                                           \
+        constexpr int TAP0 = (J) / CPP, C0 = (J) % CPP;                                           \
+        const unsigned pbc = pb + (unsigned)(C0 * pchunk);                                        \
+        /* opaque per step: otherwise hipcc hoists all fragment addresses out of the tile loop */  \
+        const int toff0 = sgpr((TAP0 / 3) * PW + TAP0 % 3);                                       \
+        if (!abl_a) {                                                                             \
+          if ((J) + 2 < NSTEP) load_a(na2, wk + ((J) + 2) * BLK);                                 \
+          else if (more_passes) load_a(na2, wnext + ((J) + 2 - NSTEP) * BLK);                     \
+        }                                                                                         \
+        if (!abl_b) load_b(bY, pbc, toff0, 64u);                                                  \
+        if (!abl_m) mfmas_kk(ca, bX, 0);                                                          \
+        if ((J) + 1 < NSTEP) {                                                                    \
+          constexpr int J1 = (J) + 1, TAP1 = J1 / CPP, C1 = J1 % CPP;                             \
+          __builtin_amdgcn_sched_barrier(0);                                                      \
+          if (!abl_b) load_b(bX, pb + (unsigned)(C1 * pchunk), sgpr((TAP1 / 3) * PW + TAP1 % 3), 0u); \
+        } else {                                                                                  \
+          __builtin_amdgcn_s_waitcnt(0xC07F);       /* my reads of this patch buffer are done */   \
+          /* my share of the next patch has landed: at least 8*HV weight loads were issued behind the DMA */ \
+          if (have_next) { if (more_passes) wait_vmcnt<8 * HV>(); else wait_vmcnt<0>(); }          \
+          if (STAMP) tq = now();                                                                  \
+          __builtin_amdgcn_s_barrier();             /* end of item: the next patch is there */    \
+          if (STAMP) t_b += now() - tq;                                                           \
+          if (more_passes) load_b(bX, pbn, 0, 0u);                                                \
+        }                                                                                         \
+        if (!abl_m) mfmas_kk(ca, bY, 1);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
       }
-      const bool startA = (((long long)item * npk) & 1) == 0;
-      int kp = 0;
-      if (!startA) { MGD_PG2_STEP(wfB, xfB, wfA, xfA) ++kp; }
-      while (kp + 2 <= npk) {
-        MGD_PG2_STEP(wfA, xfA, wfB, xfB)
-        ++kp;
-        MGD_PG2_STEP(wfB, xfB, wfA, xfA)
-        ++kp;
-      }
-      if (kp < npk) { MGD_PG2_STEP(wfA, xfA, wfB, xfB) ++kp; }
-#undef MGD_PG2_STEP
+#define MGD_PG4_TRIPLE(J) MGD_PG4_STEP(a0, a2, J) MGD_PG4_STEP(a1, a0, (J) + 1) MGD_PG4_STEP(a2, a1, (J) + 2)
+      MGD_PG4_TRIPLE(0) MGD_PG4_TRIPLE(3) MGD_PG4_TRIPLE(6)
+      if constexpr (CPP == 2) { MGD_PG4_TRIPLE(9) MGD_PG4_TRIPLE(12) MGD_PG4_TRIPLE(15) }
+#undef MGD_PG4_TRIPLE
+#undef MGD_PG4_STEP
+      wk = wnext;
     }
-    // ---- epilogue of the tile; its LDS tile lives in the patch buffer the last pass has just left
+    // ---- epilogue, one 128-channel half at a time, in the patch buffer of the tile's last pass (every wave left it at
+    //      the end-of-item barrier); the other buffer already holds (or is receiving) the next tile's first patch
     if (STAMP) tq = now();
-    __syncthreads();
     {
       unsigned char* el = pbuf + (size_t)((item - 1) & 1) * PB;
-      Epi epi;
-      epi.prefetch(a, row_dst, co0, tid, false);
-      epi.run(a, acc, el, row_dst, co0, tid);
+      const long long* rd = row_dst + par * 128;
+#pragma unroll
+      for (int h = 0; h < HV; ++h) {
+        if (abl_e) break;
+        Epi epi;
+        epi.prefetch(a, rd, co0 + h * 128, tid, false);
+        epi.template run<false, false>(a, acc[h], el, rd, co0 + h * 128, tid);
+        lds_barrier();                              // the LDS tile (and, after the last half, the buffer) is free again
+      }
     }
-    __syncthreads();
     if (STAMP) t_e += now() - tq;
   }
   if (STAMP && a.stamps && lane == 0) {
     const unsigned long long t_end = now();
-    atomicAdd(a.stamps + 0, 0ull); atomicAdd(a.stamps + 1, t_w); atomicAdd(a.stamps + 2, t_b);
-    atomicAdd(a.stamps + 3, (t_end - t_begin) - t_w - t_b - t_e); atomicAdd(a.stamps + 4, t_e);
+    atomicAdd(a.stamps + 0, 0ull); atomicAdd(a.stamps + 1, 0ull); atomicAdd(a.stamps + 2, t_b);
+    atomicAdd(a.stamps + 3, (t_end - t_begin) - t_b - t_e); atomicAdd(a.stamps + 4, t_e);
     atomicAdd(a.stamps + 5, (unsigned long long)mytiles);
   }
 }
@@ -2322,25 +2327,42 @@ int launch_gemm2(GemmArgs& a, hipStream_t st) {
 }
 
 
-template <int NST>
-int launch_pgemm2(GemmArgs& a, PgArgs g, hipStream_t st) {
-  a.tilesC = a.Co_pad / 128;
+int pgemm_mode() {
+  static int pgemm = -1;
+  if (pgemm < 0) { const char* e = getenv("MGD_PGEMM"); pgemm = e ? atoi(e) : 0; }
+  return pgemm;
+}
+// 256-channel block tiles (two 128-channel halves per wave) when the padded channel count allows; the fragment image
+// (mgd_frag_pack) and the kernel (mgd_conv_gather_gemm) agree through this one function
+int pgemm_halves(int Co_pad) { return Co_pad % 256 == 0 ? 2 : 1; }
+
+template <int CPP, int HV>
+int launch_pgemm4(GemmArgs& a, const PgArgs& pg, const void* wfrag, hipStream_t st) {
+  Pg3Args g;
+  g.wfrag = (const bf16_t*)wfrag;
+  g.NC = pg.NC; g.NR = pg.NR; g.TH = pg.TH; g.TW = pg.TW; g.PW = pg.PW; g.PP = pg.PP; g.PP8 = pg.PP8; g.PH = pg.TH + 2;
+  g.S = pg.S; g.tilesW = pg.tilesW; g.tilesR = pg.tilesR; g.npass = pg.nch / CPP;
+  const int need = 128 * (128 * 2 + 16) + 4 * 2 * 128 * 4 + 1024;
+  g.pbytes = CPP * g.PP8 * 1024 > need ? CPP * g.PP8 * 1024 : need;
+  a.tilesC = a.Co_pad / (128 * HV);
   a.nblk = a.tilesC * g.tilesR * g.tilesW;
-  size_t lds = (size_t)NST * 128 * ROWB + 2 * (size_t)g.pbytes + 320 + 128 * 8;
-  auto k = conv_pgemm2_kernel<NST>;
+  size_t lds = 2 * (size_t)g.pbytes + 320 * 4 + 2 * 128 * 8;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_pgemm2_kernel<NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_pgemm4_kernel<CPP, HV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_pgemm4_kernel<CPP, HV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_pgemm4_kernel<CPP, HV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  int grid = a.nblk < 256 ? a.nblk : 256;            // one resident block per CU
+  int grid = a.nblk < 256 ? a.nblk : 256;
   if (a.dbg & 2) {
     (void)hipGetSymbolAddress((void**)&a.stamps, HIP_SYMBOL(g_stamps));
-    hipLaunchKernelGGL((conv_pgemm2_kernel<NST, true>), dim3(grid), dim3(512), lds, st, a, g);
-    return 0;
+    hipLaunchKernelGGL((conv_pgemm4_kernel<CPP, HV, 1>), dim3(grid), dim3(256), lds, st, a, g);
+  } else if (a.dbg & 0x1E0) {
+    hipLaunchKernelGGL((conv_pgemm4_kernel<CPP, HV, 2>), dim3(grid), dim3(256), lds, st, a, g);
+  } else {
+    hipLaunchKernelGGL((conv_pgemm4_kernel<CPP, HV, 0>), dim3(grid), dim3(256), lds, st, a, g);
   }
-  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a, g);
   return 0;
 }
 
@@ -2560,20 +2582,15 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     }
   }
   // persistent resident-patch form for the 3x3 stride-1 layers with Ci >= 64 (forward and stride-1 data gradient):
-  // opt-in (MGD_PGEMM=2), slower than the forms below at batch 16
+  // opt-in (MGD_PGEMM=1; needs the fragment-ordered weight image, mgd_frag_pack), see DESIGN.md section 3
   {
-    static int pgemm = -1;
-    if (pgemm < 0) { const char* e = getenv("MGD_PGEMM"); pgemm = e ? atoi(e) : 0; }
+    const int pgemm = pgemm_mode();
     PgArgs g;
-    if (variant == 3 && pgemm == 2 && pgemm_geometry(d, &g)) {
-      // passes of <= 2 chunks, two patch buffers (each also large enough for the epilogue's LDS tile)
-      g.cpp = g.nch < 2 ? g.nch : 2;
-      g.npass = g.nch / g.cpp;
-      const int need = 128 * (128 * 2 + 16) + 8 * 2 * 128 * 4 + 1024;
-      g.pbytes = g.cpp * g.PP8 * 1024 > need ? g.cpp * g.PP8 * 1024 : need;
-      if ((size_t)4 * 16384 + 2 * (size_t)g.pbytes + 2048 <= 160 * 1024) launch_pgemm2<4>(a, g, st);
-      else launch_pgemm2<3>(a, g, st);
-      MGD_CHECK_LAUNCH("conv_gather_gemm(persistent resident patch)");
+    if (variant == 3 && pgemm != 0 && d->wfrag && pgemm_geometry(d, &g) && g.TH + 2 <= 40) {
+      const bool c2 = g.nch % 2 == 0;
+      if (pgemm_halves(d->Co_pad) == 2) { if (c2) launch_pgemm4<2, 2>(a, g, d->wfrag, st); else launch_pgemm4<1, 2>(a, g, d->wfrag, st); }
+      else { if (c2) launch_pgemm4<2, 1>(a, g, d->wfrag, st); else launch_pgemm4<1, 1>(a, g, d->wfrag, st); }
+      MGD_CHECK_LAUNCH("conv_gather_gemm(large-register resident patch)");
       return MGD_OK;
     }
   }
@@ -2603,6 +2620,19 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     }
   }
   MGD_CHECK_LAUNCH("conv_gather_gemm");
+  return MGD_OK;
+}
+
+extern "C" int mgd_frag_pack(const void* packed, void* frag, int Co_pad, int K_pad, int Ci, void* stream) {
+  MGD_REQUIRE(packed && frag, "frag_pack: null pointer");
+  MGD_REQUIRE(Co_pad % 128 == 0 && Ci % 64 == 0 && K_pad == 9 * Ci, "frag_pack: needs Co_pad %% 128 == 0, Ci %% 64 == 0, K_pad == 9*Ci");
+  const int cpp = (Ci / 64) % 2 == 0 ? 2 : 1;
+  long long nchunk = (long long)Co_pad * K_pad / 8;
+  long long g = (nchunk + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  hipLaunchKernelGGL(frag_pack_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const uint4*)packed, (uint4*)frag, K_pad,
+                     Ci, cpp, pgemm_halves(Co_pad), nchunk);
+  MGD_CHECK_LAUNCH("frag_pack");
   return MGD_OK;
 }
 

@@ -945,10 +945,11 @@ def test_per_scale_nms_option_vs_oracle(dev):
 
 
 def test_persistent_resident_patch_gemm_opt_in(dev):
-    """MGD_PGEMM=2 (read once per process, hence a child process): the persistent resident-patch form of the 3x3 stride-1
-    gather-GEMM (conv_pgemm2_kernel: input patch staged once per tile, weight ring, patches prefetched across tiles) must
-    agree with the default kernels - forward with BatchNorm statistics, and the data gradient with addend - on every tile
-    geometry (1x16, 2x8 and 4x4 n-tiles; one to eight passes; maps smaller than a tile; tiles spanning images)."""
+    """MGD_PGEMM=1 (read once per process, hence a child process): the persistent resident-patch form of the 3x3 stride-1
+    gather-GEMM (conv_pgemm4_kernel: input patch staged once per pass, fragment-ordered weights from mgd_frag_pack, 256- and
+    128-channel block tiles, one or two 64-channel chunks per pass) must agree with the default kernels - forward with
+    BatchNorm statistics, and the data gradient with addend - on every tile geometry (1x16, 2x8 and 4x4 n-tiles; one to
+    eight passes; maps smaller than a tile; tiles spanning images)."""
     import subprocess, sys
     code = r"""
 import sys, torch
@@ -956,7 +957,7 @@ sys.path.insert(0, %r)
 from multigriddet_amd import ops
 dev = torch.device('cuda:0')
 cases = [(2, 20, 20, 64, 128), (3, 5, 7, 64, 128), (2, 19, 19, 512, 1024), (2, 38, 38, 256, 512), (2, 76, 76, 128, 256),
-         (1, 21, 37, 256, 128), (16, 19, 19, 256, 512)]
+         (1, 21, 37, 256, 128), (16, 19, 19, 256, 512), (2, 9, 9, 64, 256), (1, 16, 16, 192, 384)]
 g = torch.Generator().manual_seed(3)
 out = {}
 for (N, H, W, Ci, Co) in cases:
@@ -976,7 +977,7 @@ torch.save(out, sys.argv[1])
     from conftest import ROOT as _R
     res = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for tag, env in (("default", {}), ("pgemm", {"MGD_PGEMM": "2"})):
+        for tag, env in (("default", {}), ("pgemm", {"MGD_PGEMM": "1"})):
             path = os.path.join(tmp, tag + ".pt")
             r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True)
             assert r.returncode == 0, r.stdout + r.stderr

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Ablation timing of the persistent resident-patch kernel on one layer (MGD_DBG bits: 32 no epilogue, 64 no MFMA,
-128 no fragment reads, 256 no ring DMA, 512 no patch DMA).  usage: MGD_DBG=<bits> python tools/ablate_pg.py cin cout H"""
+128 no pixel-fragment reads, 256 no weight-fragment loads; any of them selects the kernel's ablation build).
+usage: MGD_PGEMM=1 MGD_DBG=<bits> python tools/ablate_pg.py cin cout H"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

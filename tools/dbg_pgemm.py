@@ -7,7 +7,7 @@ from multigriddet_amd import ops
 
 dev = torch.device("cuda:0")
 shapes = [(2, 20, 20, 64, 128), (1, 8, 16, 64, 128), (2, 19, 19, 128, 128), (1, 38, 38, 128, 256), (2, 76, 76, 128, 256),
-          (2, 19, 19, 512, 256), (3, 5, 7, 64, 128), (1, 16, 16, 256, 128)]
+          (2, 19, 19, 512, 256), (3, 5, 7, 64, 128), (1, 16, 16, 256, 128), (1, 19, 19, 256, 512), (2, 9, 9, 64, 256)]
 for (N, H, W, Ci, Co) in shapes:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(N, H, W, Ci, generator=g).to(torch.bfloat16)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: where a wave of the resident-patch gather-GEMM spends its cycles (stamped build, MGD_DBG=2).
-usage: MGD_DBG=2 [MGD_PGEMM=1|2] python tools/stamps_pg.py cin cout H [B]"""
+usage: MGD_DBG=2 [MGD_PGEMM=1] python tools/stamps_pg.py cin cout H [B]"""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
