@@ -141,13 +141,14 @@ def infer_bench(dev, size, steps=20, warmup=3):
 def pmc_traffic(prefix="conv_gemm2_kernel<2, 2, 4, 4, 2"):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (collected in separate
     rocprofv3 --pmc passes of this same command; FETCH_SIZE x2 on gfx950 + WRITE_SIZE); (None, reason) if absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.txt")
-    try:
-        for line in open(path):
-            if line.startswith(prefix):
-                return int(float(line.split("|")[-1]) * 1024 * 1024), "profiles/r01_pmc_traffic.txt (separate --pmc passes)"
-    except OSError:
-        pass
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for name in ("r02_pmc_traffic.txt", "r01_pmc_traffic.txt"):          # newest committed summary first
+        try:
+            for line in open(os.path.join(root, name)):
+                if line.startswith(prefix):
+                    return int(float(line.split("|")[-1]) * 1024 * 1024), f"profiles/{name} (separate --pmc passes)"
+        except OSError:
+            pass
     return None, "no PMC summary found"
 
 
