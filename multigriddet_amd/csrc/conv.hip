@@ -1366,6 +1366,7 @@ struct WgradArgs {
   int chunk;      // pixels per split (multiple of 64)
   int splits, tilesCo, tilesCi;
   float rcp_hw, rcp_w;
+  int dbg;        // diagnostics (MGD_DBG): 16 = plain stores instead of atomics, 32 = no epilogue at all
 };
 
 __device__ __forceinline__ int tr_swz(int row, int nchunk32) {
@@ -1418,7 +1419,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / WI, wi = wave % WI;
 
   int b = blockIdx.x;
@@ -1433,44 +1434,80 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
   const int pend = min(a.P, pbeg + a.chunk);
   const int nk = (pend - pbeg + 63) / 64;
   const void* zero = (const void*)g_zero_page;
+  asm volatile("" : "+s"(zero));
 
   // per-thread (row-in-group, logical chunk) for both tiles
   const int o_rl = lane / (RBO / 16), o_s = lane % (RBO / 16);
   const int i_rl = lane / (RBI / 16), i_s = lane % (RBI / 16);
 
-  auto issue = [&](int ks, int buf) {
-    const int p0 = pbeg + ks * 64;
+  // Address generation off the critical path.  K runs over PIXELS here, so the rows a lane stages change every K-step;
+  // the first version re-derived (image, row, column) of every row from its flat pixel index per step - two divisions
+  // with correction loops per LDS-DMA instruction, 510 VALU + 395 SALU instructions per 32 MFMA (ISA count), the loop was
+  // bound by instruction issue, not by the matrix cores or the DMA.  A lane's rows advance by exactly 64 pixels per K-step,
+  // so (image, row, column) are carried and advanced with a compare-and-wrap; the row's channel chunk never changes.
+  // Uniform values are pinned in SGPRs (a scalar re-load from the argument segment inside the loop drains lgkmcnt).
+  const int Wg = sgpr(a.Wg), Hg = sgpr(a.Hg), Hs = sgpr(a.Hs), Ws = sgpr(a.Ws), Ci = sgpr(a.Ci), Co = sgpr(a.Co);
+  const int sst = sgpr(a.in_stride), q64 = sgpr(64 / a.Wg), r64 = sgpr(64 % a.Wg);
+  const int wraps = sgpr((64 / a.Wg + 1 + a.Hg - 1) / a.Hg);            // image wraps one 64-pixel advance can cross
+  const char* srcb = (const char*)a.src;
+  const char* dyb = (const char*)a.dy;
+  int o_cb[OCH];                 // byte offset of the lane's dy chunk inside a pixel row, or -1 (channel padding)
+  long long o_off[OCH];          // byte offset of the lane's dy chunk at the next K-step to issue
+  int o_p[OCH];
+#pragma unroll
+  for (int i = 0; i < OCH; ++i) {
+    const int r = (i * 4 + wave) * ORPI + o_rl;
+    const int ch = (((o_s >> 1) ^ tr_swz(r, RBO / 32)) << 1) | (o_s & 1);
+    const int c = co0 + ch * 8;
+    o_cb[i] = c < Co ? c * 2 : -1;
+    o_p[i] = pbeg + r;
+    o_off[i] = (long long)o_p[i] * Co * 2 + c * 2;
+  }
+  int x_cb[ICH], x_p[ICH], x_n[ICH], x_i[ICH], x_j[ICH];
+#pragma unroll
+  for (int i = 0; i < ICH; ++i) {
+    const int r = (i * 4 + wave) * IRPI + i_rl;
+    const int ch = (((i_s >> 1) ^ tr_swz(r, RBI / 32)) << 1) | (i_s & 1);
+    const int c = ci0 + ch * 8;
+    x_cb[i] = c < Ci ? c * 2 : -1;
+    const int pix = pbeg + r, hw = a.Hg * a.Wg;
+    x_p[i] = pix;
+    x_n[i] = pix / hw;
+    const int rem = pix - x_n[i] * hw;
+    x_i[i] = rem / a.Wg;
+    x_j[i] = rem - x_i[i] * a.Wg;
+  }
+
+  // stages the NEXT K-step (steps are issued in order, each exactly once) into ring slot buf
+  auto issue_o = [&](int buf) {
     unsigned char* ob = smem + buf * STAGE;
-    unsigned char* ib = ob + 64 * RBO;
 #pragma unroll
     for (int i = 0; i < OCH; ++i) {
-      int r = (i * 4 + wave) * ORPI + o_rl;
-      int ch = (((o_s >> 1) ^ tr_swz(r, RBO / 32)) << 1) | (o_s & 1);
-      int p = p0 + r, c = co0 + ch * 8;
-      const void* g = (p < pend && c < a.Co) ? (const void*)(a.dy + (long long)p * a.Co + c) : zero;
-      glds16(g, ob + (i * 4 + wave) * 1024);
+      const bool v = o_p[i] < pend && o_cb[i] >= 0;
+      glds16(v ? (const void*)(dyb + o_off[i]) : zero, ob + (i * 4 + wave) * 1024);
+      o_p[i] += 64;
+      o_off[i] += (long long)Co * 128;
     }
+  };
+  auto issue_x = [&](int buf) {
+    unsigned char* ib = smem + buf * STAGE + 64 * RBO;
 #pragma unroll
     for (int i = 0; i < ICH; ++i) {
-      int r = (i * 4 + wave) * IRPI + i_rl;
-      int ch = (((i_s >> 1) ^ tr_swz(r, RBI / 32)) << 1) | (i_s & 1);
-      int p = p0 + r, c = ci0 + ch * 8;
-      const void* g = zero;
-      if (p < pend && c < a.Ci) {
-        const int hw = a.Hg * a.Wg;
-        int n = (int)((float)p * a.rcp_hw);
-        int rem = p - n * hw;
-        while (rem < 0) { --n; rem += hw; }
-        while (rem >= hw) { ++n; rem -= hw; }
-        int ig = (int)((float)rem * a.rcp_w);
-        int jg = rem - ig * a.Wg;
-        while (jg < 0) { --ig; jg += a.Wg; }
-        while (jg >= a.Wg) { ++ig; jg -= a.Wg; }
-        int hs = ig * a.in_stride + dh, ws = jg * a.in_stride + dw;
-        if ((unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws)
-          g = (const void*)(a.src + (((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci + c);
+      const int hs = x_i[i] * sst + dh, ws = x_j[i] * sst + dw;
+      const bool v = x_p[i] < pend && x_cb[i] >= 0 && (unsigned)hs < (unsigned)Hs && (unsigned)ws < (unsigned)Ws;
+      const int lin = (x_n[i] * Hs + hs) * Ws + ws;
+      glds16(v ? (const void*)(srcb + (long long)lin * (Ci * 2) + x_cb[i]) : zero, ib + (i * 4 + wave) * 1024);
+      x_p[i] += 64;
+      x_j[i] += r64;
+      x_i[i] += q64;
+      const int cj = x_j[i] >= Wg ? 1 : 0;               // branch-free carries: exec-mask branches cost more than the selects
+      x_j[i] -= cj ? Wg : 0;
+      x_i[i] += cj;
+      for (int w = 0; w < wraps; ++w) {
+        const int cn = x_i[i] >= Hg ? 1 : 0;
+        x_i[i] -= cn ? Hg : 0;
+        x_n[i] += cn;
       }
-      glds16(g, ib + (i * 4 + wave) * 1024);
     }
   };
 
@@ -1480,7 +1517,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) issue(0, 0);
+  if (nk > 0) { issue_o(0); issue_x(0); }
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
   // fragment read offsets inside a stage: MFMA k index = pixel row kk*32 + 8g + qq (+4 for the upper half)
   int o_rd[2][2][MT], i_rd[2][2][NT];
@@ -1503,7 +1540,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
   for (int ks = 0; ks < nk; ++ks) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
+    const bool more = ks + 1 < nk;
     const unsigned sb = smem_a + (ks & 1) * STAGE;
     s16x4 fa[2][MT][2], fb[2][NT][2];
     auto read_half = [&](int kk) {
@@ -1534,6 +1571,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
         }
       }
     };
+    // the next stage goes out FIRST: with a two-deep ring its round trip is the step's critical path (issuing the input
+    // half behind the first MFMAs instead cost 75 %)
+    if (more) { issue_o((ks + 1) & 1); issue_x((ks + 1) & 1); }
     read_half(0);
     wait_lgkm_dyn(0);
     read_half(1);          // in flight under the MFMAs of the first half
@@ -1560,7 +1600,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
     int co = co0 + col, ci = ci0 + cil;
     if (co < a.Co && ci < a.Ci) {
       float v = *(const float*)(smem + col * EROW + cil * 4);
-      atomicAdd(a.dw + ((long long)co * a.ntaps + tap) * a.Ci + ci, v);
+      float* dst = a.dw + ((long long)co * a.ntaps + tap) * a.Ci + ci;
+      if (a.dbg & 32) continue;
+      if (a.dbg & 16) *dst = v; else atomicAdd(dst, v);
     }
   }
 }
@@ -2694,6 +2736,7 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
   a.splits = cdiv(a.P, a.chunk);
   a.rcp_hw = 1.0f / (float)(d->Hg * d->Wg);
   a.rcp_w = 1.0f / (float)d->Wg;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MGD_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
   hipStream_t st = (hipStream_t)stream;
   int co = d->Co, ci = d->Ci;
   static int wvariant = -1;
