@@ -44,7 +44,8 @@ int mgd_version(void);
  * source pixel is (i*in_stride + dh[t], j*in_stride + dw[t]) (zero outside the source) and the
  * destination pixel is (i*out_stride + out_off_h, j*out_stride + out_off_w).
  *   dst[n, ., ., co] = sum_{t, ci} src[n, ., ., ci] * wpk[co][t*Ci + ci]  (+ bias[co]) (+ addend)
- * `wpk` is a packed bf16 weight image [Co_pad][K_pad] produced by mgd_pack_weights.
+ * `wpk` is a packed bf16 weight image [Co_pad][K_pad] produced by mgd_pack_weights / mgd_pack_weights_batch
+ * (opaque: row-major for 32- and 64-row tiles, MFMA-fragment order when Co_pad % 128 == 0, see mgd_pack_weights).
  * Optional epilogues: per-channel sum / sum-of-squares of the (bf16-rounded) result into
  * `stats[(block % stats_replicas)][2][Co]` for training-mode BatchNorm; fp32 output.
  * Limits (MGD_EINVAL otherwise): N*Hg*Wg < 2^31 pixels; the kernels address `src` and `wpk` with 32-bit byte
@@ -82,17 +83,10 @@ typedef struct mgd_conv_desc {
    * act_slope != 0 applies LeakyReLU(act_slope) to (acc + bias) before the optional `addend` (= the residual input),
    * i.e. the whole DarknetConv2D_BN_Leaky (+ Add) of models/layers.py:88-95 in one launch.  bf16 output only. */
   float act_slope;
-  /* optional: the same weights in MFMA-fragment order (mgd_frag_pack); enables the persistent resident-patch form of
-   * the 3x3 stride-1 gather-GEMM when the library runs with MGD_PGEMM=1 */
-  const void* wfrag;
 } mgd_conv_desc;
 
 int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream);
-/* Re-lays a packed 3x3 image [Co_pad][K_pad = 9*Ci] (Co_pad % 128 == 0, Ci % 64 == 0) out in MFMA-fragment order: per
- * (channel tile of 128, or 256 when Co_pad % 256 == 0; pass of 64 or 128 input channels; K-step) one block
- * [wave(4)][half][m(2)][kk(2)][lane(64)] x 16 B, so that a wave's A operand is coalesced 1-KiB loads.  The image is opaque:
- * written here, read by mgd_conv_gather_gemm through mgd_conv_desc.wfrag.  frag has the size of packed. */
-int mgd_frag_pack(const void* packed, void* frag, int Co_pad, int K_pad, int Ci, void* stream);
+
 
 /* Stride-2 data gradient of a 3x3 conv with 32 input / 64 output channels (the first down-sampling layer,
  * models/backbones/darknet.py:33-34 with ZeroPadding2D(((1,0),(1,0))): all four output-parity classes in one launch,
@@ -149,7 +143,11 @@ int mgd_stem_wgrad_bn(const float* image, const void* da, const void* y, const f
 
 /* Pack fp32 master weights W[Co][T][Ci] (OHWI) into a bf16 gather-GEMM image.
  * out[r][t'*Cin' + c] = transpose ? W[c][src_tap[t']][r] : W[r][src_tap[t']][c], zero padded to
- * [rows_pad][K_pad].  (transpose=1 builds data-gradient images.) */
+ * [rows_pad][K_pad].  (transpose=1 builds data-gradient images.)
+ * Element (r, k) is stored row-major when rows_pad % 128 != 0.  When rows_pad % 128 == 0 (K_pad % 64 == 0) the image is in
+ * MFMA-fragment order: per (128-row tile cot, 64-deep K-step ks) one 16-KiB block of 1024 16-byte chunks, chunk
+ * ((g*2 + kk)*64 + lane) holding row cot*128 + g*16 + (lane & 15), columns ks*64 + (kk*4 + (lane >> 4))*8 .. +8
+ * (g = 16-row group 0..7, kk = 32-deep half) - a wave's A operand of a K-step is then eight coalesced 16-byte loads. */
 int mgd_pack_weights(const float* w, void* out, int Co, int T, int Ci, int transpose, int ntaps_out,
                      const int32_t* src_tap_host, int rows_pad, int K_pad, void* stream);
 

@@ -35,6 +35,7 @@ struct GemmArgs {
   int M;        // N*Hg*Wg
   int tilesC;   // Co_pad / BNC
   int nblk;
+  int aux;      // conv_gemm8_kernel: byte offset of row_dst in LDS (behind the ring / the epilogue tile)
   int dbg;      // diagnostic only (MGD_DBG): 1 = all LDS-DMA loads hit one cache line, 2 = phase stamps
   unsigned long long* stamps;
   // fused BN-backward reduction of the CONSUMER layer over the tile just produced (dst = da of that layer)
@@ -78,6 +79,13 @@ __device__ __forceinline__ void lds_barrier() {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// the same wait through the builtin: hipcc's own wait-count bookkeeping sees it (after an asm wait it still assumes the
+// loads outstanding and adds a full s_waitcnt vmcnt(0) in front of their first use)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_tracked() {
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
 template <int WC, int WP, int MT, int NT, int NST, bool STAMP = false>
@@ -160,9 +168,10 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
   // thread -> LDS slot (tid & 7) of rows (tid >> 3) + RPR i ; source chunk kc = slot ^ (row & 7).
   // Address generation is kept off the critical path (the first version spent 5.7 VALU instructions
   // per MFMA on it): per row a 32-bit byte offset and a 9-bit tap-validity mask are computed once; per
-  // K-step a load costs a mask test, a select and an add, with the tensor base in SGPRs.  Out-of-image
-  // taps load from offset 0 (any valid address) and the owning lane overwrites its 16-byte LDS slot
-  // with zeros once its own DMA has landed (before the barrier that publishes the stage).
+  // K-step a load costs a mask test, a select and an add.  Out-of-image taps load from a zero page.  (They used to
+  // load from offset 0 with the owning lane zeroing its LDS slot once the DMA had landed: in front of that ds_write hipcc
+  // puts s_waitcnt vmcnt(0) - it may alias the LDS-DMA writes in flight - and the fix-up sat between the wait and the
+  // barrier of most K-steps of a 3x3 layer; without it the 128-tile launches are 5-9 % faster.)
   const int rlo = tid >> 3;
   const int kc = (tid & 7) ^ (rlo & 7);
   unsigned xoff[XCH];
@@ -193,7 +202,8 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
   const char* wbase = (const char*)a.wpk;
   // my LDS slots (byte offsets inside a stage) for the zero fix-up
 
-  unsigned inv_next = 0;
+  const void* zero = (const void*)g_zero_page;
+  asm volatile("" : "+s"(zero));
   auto issue = [&](int ks, int buf) {
     unsigned char* wb = smem + buf * STAGE + wave * 1024;
     unsigned char* xb = smem + buf * STAGE + BNC * ROWB + wave * 1024;
@@ -203,14 +213,12 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
     int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
     int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
     int toff = ((dh * a.Ws + dw) * a.Ci + cch) * 2;
-    inv_next = 0;
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
       bool v = (vmask[i] >> tap) & 1u;
-      unsigned off = v ? xoff[i] + (unsigned)toff : 0u;
+      unsigned off = xoff[i] + (unsigned)toff;
       if (a.dbg & 1) off = 0u;
-      if (!v) inv_next |= 1u << i;
-      glds16(xbase + off, xb + i * (RPR * ROWB));
+      glds16(v ? (const void*)(xbase + off) : zero, xb + i * (RPR * ROWB));
     }
     cch += BK;
     while (cch >= a.Ci) {
@@ -226,13 +234,9 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = a.K_pad / BK;
-  // ring bookkeeping of the zero fix-up masks: stage s issued -> inv[s % NST]
-  unsigned inv[NST];
-#pragma unroll
-  for (int s = 0; s < NST; ++s) inv[s] = 0;
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) { issue(s, s); inv[s] = inv_next; }
+    if (s < nk) issue(s, s);
 
   const int fr = lane & 15, fq = lane >> 4;
   // fragment read offsets inside a stage (k-half kk flips bit 6 of the byte offset)
@@ -241,7 +245,6 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
   for (int m = 0; m < MT; ++m) wro[m] = lds_off((wc * MT + m) * 16 + fr, fq);
 #pragma unroll
   for (int n = 0; n < NT; ++n) xro[n] = BNC * ROWB + lds_off((wp * NT + n) * 16 + fr, fq);
-  const int zslot = BNC * ROWB + (rlo * ROWB) + (tid & 7) * 16;   // + i * RPR*ROWB : my X slots
 
   // diagnostic build only (STAMP): cycles per phase of the K-loop, summed per wave, one atomic per wave at
   // the end into a.stamps[0..4] = {wait vmcnt, zero-fix + barrier, LDS-DMA issue, fragment reads + MFMA, loops}
@@ -260,24 +263,9 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
     if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp(); tw += t1 - t0; __builtin_amdgcn_sched_barrier(0); }
     const int cur = ks % NST;
     unsigned char* sb = smem + cur * STAGE;
-    unsigned invc = 0;
-#pragma unroll
-    for (int s = 0; s < NST; ++s)
-      if (s == cur) invc = inv[s];
-    if (invc) {
-#pragma unroll
-      for (int i = 0; i < XCH; ++i)
-        if (invc & (1u << i)) *(uint4*)(sb + zslot + i * (RPR * ROWB)) = make_uint4(0, 0, 0, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (STAMP) { __builtin_amdgcn_sched_barrier(0); t0 = stamp(); tb += t0 - t1; __builtin_amdgcn_sched_barrier(0); }
-    if (ks + NST - 1 < nk) {
-      issue(ks + NST - 1, (ks + NST - 1) % NST);
-#pragma unroll
-      for (int s = 0; s < NST; ++s)
-        if (s == (ks + NST - 1) % NST) inv[s] = inv_next;
-    }
+    if (ks + NST - 1 < nk) issue(ks + NST - 1, (ks + NST - 1) % NST);
     if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp(); ti += t1 - t0; __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -709,18 +697,18 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
     }
     int tap = (kc * 8) / a.Ci;
     int cch = (kc * 8) - tap * a.Ci;
-    unsigned woff[WCH];
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) woff[i] = (unsigned)(((long long)(co0 + rlo + 32 * i) * a.K_pad + kc * 8) * 2);
+    // weights: the packed image is in fragment order (packed_elem) - the tile of K-step s is one contiguous 16-KiB block,
+    // copied as it lies (piece i of this thread = chunks i*256 + ltid), and the consumers read it back lane-linear
+    static_assert(BNC == 128, "fragment-ordered weight tiles are 128 rows");
     const char* xbase = (const char*)a.src;
-    const char* wbase = (const char*)a.wpk;
+    const char* wbase = (const char*)a.wpk + ((size_t)tc * nk * 16384) + (size_t)ltid * 16;
     const void* zero = (const void*)g_zero_page;
 
     auto issue = [&](int s, int slot) {
       unsigned char* wb = smem + slot * STAGE + wave * 1024;
       unsigned char* xb = wb + BNC * ROWB;
 #pragma unroll
-      for (int i = 0; i < WCH; ++i) glds16(wbase + woff[i] + (unsigned)s * (BK * 2), wb + i * (32 * ROWB));
+      for (int i = 0; i < WCH; ++i) glds16(wbase + (size_t)s * 16384 + i * 4096, wb + i * (32 * ROWB));
       int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
       int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
       int toff = ((dh * a.Ws + dw) * a.Ci + cch) * 2;
@@ -762,7 +750,7 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
   const int fr = lane & 15, fq = lane >> 4;
   int wro[MT], xro[NT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) wro[m] = lds_off((wc * MT + m) * 16 + fr, fq);
+  for (int m = 0; m < MT; ++m) wro[m] = (wc * MT + m) * 2048 + lane * 16;   // fragment (m, kk) = 1 KiB, lane-linear
 #pragma unroll
   for (int n = 0; n < NT; ++n) xro[n] = BNC * ROWB + lds_off((wp * NT + n) * 16 + fr, fq);
   int slot = 0;
@@ -773,7 +761,7 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 wf[MT], xf[NT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(sb + (wro[m] ^ (kk << 6)));
+      for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(sb + wro[m] + kk * 1024);
 #pragma unroll
       for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + (xro[n] ^ (kk << 6)));
 #pragma unroll
@@ -790,300 +778,177 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// "Resident patch" form of the 3x3 stride-1 gather-GEMM (forward and stride-1 data gradient) for Ci >= 64 (opt-in:
-// MGD_PGEMM=1; at batch 16 within a few percent of the gather-GEMMs above either way).
-//
-// The gather-GEMMs above stream BOTH operands through LDS-DMA every K-step: 32 KB per 128 x 128 x 64 step, and a CU takes
-// in ~32 B/clk from L2 (MI355X_MICROARCH.md: 66-73 GB/s per CU), i.e. >= 1000 cycles of DMA against 512 cycles of MFMA.
-// A 3x3 conv re-reads every input pixel nine times; here the haloed input patch of the block's 128 output pixels is
-// staged in LDS ONCE per pass (64-channel chunks, same XOR-swizzled 128-byte rows as the ring) and the nine taps read it
-// at shifted pixel indices.  Out-of-image pixels come from a zero page when the patch is loaded: no per-tap masks, no
-// zero fix-ups in the loop.
-//
-// Pixel tile: 8 MFMA n-tiles of 16 pixels, an n-tile being NR rows x NC columns (NC = 16 / 8 / 4 chosen so that the map
-// width wastes least), stacked vertically: TH = 8*NR rows x TW = NC columns.  Rows run over the whole batch in "stacked"
-// coordinates Rs = n*(H+1) + h: one virtual zero row separates consecutive images (it is the bottom padding of image n and
-// the top padding of image n+1 at once), so tiles may span images and maps of any height tile without per-image waste.
-// K order: pass-major (a pass = up to 4 chunks of 64 input channels resident at once), then tap, then chunk.
-struct PgArgs {
-  int NC, NR, TH, TW, PW, PP, PP8;   // n-tile shape, tile, patch width, patch pixels, ceil(PP / 8)
-  int S;                             // stacked rows N*(H+1) - 1
-  int tilesW, tilesR;
-  int nch, cpp, npass;               // 64-channel chunks, chunks per pass, passes
-  int pbytes;                        // persistent form: bytes of one patch buffer
-};
+// Gather-GEMM for 128-channel tiles: the WEIGHT operand comes straight from global memory.
+// An LDS-DMA instruction costs its wave ~125 cycles of issue time per 1-KiB piece; with both operands staged that way a wave
+// spent eight of them per K-step (4 weight + 4 pixel pieces) in front of 32 MFMA = 512 cycles.  The weights need no gather
+// and no transposition: the packed image of a 128-row tile is stored in MFMA-fragment order (packed_elem), so a wave's A
+// operand of a K-step is eight plain, fully coalesced global_load_dwordx4 (vector-memory path: L1/TA, a fraction of the
+// issue cost), loaded NST - 1 K-steps ahead into spare register sets.  The LDS-DMA ring carries the gathered pixel tile
+// only: half the pieces, half the ring (16 KB per stage), no LDS reads for the weight fragments - and the block needs so
+// little LDS (40 KB) and so few registers (165) that THREE blocks share a CU (three waves per SIMD).  Measured against the
+// form with both operands in the ring (conv_gemm2_kernel<2,2,4,4,2>, since removed), 608x608 batch 16: 128->256 at 76x76
+// 79 -> 68 us, 256->512 at 38x38 74 -> 64 us, 64->128 at 152x152 103 -> 85 us; a deeper ring (NST = 3, 4) is not faster.
+// Tile 128 x 128, 4 waves of 64 x 64, epilogue = GemmEpilogue.
+template <int NST, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void conv_gemm8_kernel(GemmArgs a) {
+  constexpr int WC = 2, WP = 2, MT = 4, NT = 4, BNC = 128, BMP = 128, NTHR = 256;
+  constexpr int RPR = NTHR / 8, XCH = BMP / RPR;          // 32 rows per LDS-DMA round, 4 pixel pieces per wave and stage
+  constexpr int STAGE = BMP * ROWB;
+  using Epi = GemmEpilogue<WC, WP, MT, NT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  long long* row_dst = (long long*)(smem + a.aux);   // behind max(ring, epilogue tile): the fp32 tile of the heads is larger
 
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave / WP, wp = wave % WP;
+  const int L = xcd_remap(blockIdx.x, a.nblk);
+  const int tc = L % a.tilesC, tp = L / a.tilesC;
+  const int co0 = tc * BNC, pix0 = tp * BMP;
+  const int nk = a.K_pad / BK;
+
+  if (tid < BMP) {
+    int m = pix0 + tid;
+    long long off = -1;
+    if (m < a.M) {
+      int hw = a.Hg * a.Wg;
+      int n = m / hw, rem = m - n * hw;
+      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+      int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
+      off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
+    }
+    row_dst[tid] = off;
+  }
+  Epi epi;                                           // its HBM operands are fetched late (run<.., LATE>): fetched here they
+  //                                                    cost 52 bytes of scratch under the 256-register cap of two waves per SIMD
+
+  // pixel rows of this thread (as conv_gemm2_kernel): byte offset + tap-validity mask once, per K-step a select and an add
+  const int rlo = tid >> 3;
+  const int kc = (tid & 7) ^ (rlo & 7);
+  unsigned xoff[XCH], vmask[XCH];
+#pragma unroll
+  for (int i = 0; i < XCH; ++i) {
+    int m = pix0 + rlo + RPR * i;
+    xoff[i] = 0; vmask[i] = 0;
+    if (m < a.M) {
+      int hw = a.Hg * a.Wg;
+      int n = m / hw, rem = m - n * hw;
+      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+      int hs = ig * a.in_stride, ws = jg * a.in_stride;
+      xoff[i] = (unsigned)(((((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci) * 2);
+      for (int t = 0; t < a.ntaps; ++t) {
+        int dh = (int)((a.tapcode >> (4 * t)) & 3) - 1, dw = (int)((a.tapcode >> (4 * t + 2)) & 3) - 1;
+        if ((unsigned)(hs + dh) < (unsigned)a.Hs && (unsigned)(ws + dw) < (unsigned)a.Ws) vmask[i] |= 1u << t;
+      }
+    }
+  }
+  int tap = (kc * 8) / a.Ci;
+  int cch = (kc * 8) - tap * a.Ci;
+  // out-of-image taps are fetched from a zero page (64-bit per-lane source addresses): conv_gemm2_kernel loads them from
+  // offset 0 and overwrites the LDS slot with zeros afterwards, and in front of that ds_write hipcc puts s_waitcnt vmcnt(0)
+  // (it may alias the LDS-DMA writes in flight) - harmless with two stages, but it drains any deeper ring on every K-step
+  // whose tap leaves the image for some lane, i.e. on most of them
+  const char* xbase = (const char*)a.src;
+  const void* zero = (const void*)g_zero_page;
+  asm volatile("" : "+s"(zero));
+  auto issue = [&](int buf) {                          // stages go out in order
+    unsigned char* xb = smem + buf * STAGE + wave * 1024;
+    const int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
+    const int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
+    const int toff = ((dh * a.Ws + dw) * a.Ci + cch) * 2;
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const bool v = (vmask[i] >> tap) & 1u;
+      glds16(v ? (const void*)(xbase + (xoff[i] + (unsigned)toff)) : zero, xb + i * (RPR * ROWB));
+    }
+    cch += BK;
+    while (cch >= a.Ci) { cch -= a.Ci; ++tap; }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int xro[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) xro[n] = lds_off((wp * NT + n) * 16 + fr, fq);
+  // weight fragments: block (tc, ks) = 1024 chunks of 16 B; this wave's eight start at wc*512.  NST register sets: the
+  // set of step ks + NST - 1 is requested together with ring stage ks + NST - 1, so both operands have NST - 1 K-steps
+  // to arrive (with a single step of distance the round trip of the weight loads sets the K-step, whatever the ring depth)
+  const uint4* wl = (const uint4*)a.wpk + ((size_t)tc * nk * 16 + (size_t)wc * 8) * 64 + lane;
+  bf16x8 af[NST][MT][2];
+  auto load_a = [&](bf16x8 (&f)[MT][2], int ks) {
+    const uint4* w = wl + (size_t)ks * 1024;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) f[m][kk] = __builtin_bit_cast(bf16x8, w[(m * 2 + kk) * 64]);
+  };
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) { issue(s); load_a(af[s], s); }
+
+  constexpr int GRP = XCH + 2 * MT;                    // vector-memory instructions per stage: 4 LDS-DMA + 8 fragment loads
+  for (int ks0 = 0; ks0 < nk; ks0 += NST) {
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      const int ks = ks0 + j;
+      if (ks >= nk) break;
+      const int younger = min(NST - 2, nk - 1 - ks);   // stage groups behind this one that may stay in flight
+      if (NST >= 4 && younger >= 2) wait_vmcnt_tracked<2 * GRP>();
+      else if (NST >= 3 && younger == 1) wait_vmcnt_tracked<GRP>();
+      else wait_vmcnt_tracked<0>();
+      unsigned char* sb = smem + j * STAGE;
+      __builtin_amdgcn_s_barrier();
+      const int jn = (j + NST - 1) % NST;               // static after unrolling
+      if (ks + NST - 1 < nk) {
+        issue(jn);
+        load_a(af[jn], ks + NST - 1);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 xf[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + (xro[n] ^ (kk << 6)));
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][m][kk], xf[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  epi.template run<false, true>(a, acc, smem, row_dst, co0, tid);
+}
+
+template <int NST, int WPE>
+int launch_gemm8(GemmArgs& a, hipStream_t st) {
+  a.tilesC = a.Co_pad / 128;
+  a.nblk = a.tilesC * cdiv(a.M, 128);
+  size_t ring = (size_t)NST * 128 * ROWB;
+  size_t epi = a.dst_f32 ? (size_t)128 * (128 * 4 + 16) : (size_t)128 * (128 * 2 + 16) + 4 * 2 * 128 * 4;
+  a.aux = (int)(ring > epi ? ring : epi);
+  size_t lds = (size_t)a.aux + 128 * 8 + 64;
+  auto k = conv_gemm8_kernel<NST, WPE>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), lds, st, a);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // keeps a wave-uniform value in an SGPR and opaque to the compiler: it can then neither be re-loaded from the kernel
-// argument segment inside the K-loop (a scalar load there forces s_waitcnt lgkmcnt(0) in front of the MFMAs and with it
+// argument segment inside a K-loop (a scalar load there forces s_waitcnt lgkmcnt(0) in front of the MFMAs and with it
 // the just-issued fragment reads of the NEXT step) nor folded back into a longer expression
 __device__ __forceinline__ int sgpr(int v) {
   asm volatile("" : "+s"(v));
   return v;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Arguments of the persistent resident-patch kernel.  The weights come from a second packed image in MFMA-fragment order
-// (frag_pack_kernel): a wave's A operand is then plain, fully coalesced 16-byte global loads straight into registers, not
-// an LDS round trip.
-struct Pg3Args {
-  const bf16_t* wfrag;               // fragment-ordered weights
-  int NC, NR, TH, TW, PW, PP, PP8, PH;
-  int S, tilesW, tilesR, npass;
-  int pbytes;                        // bytes of one patch buffer (>= CPP * PP8 * 1024 and >= the epilogue's LDS tile)
-};
-
-// fragment-ordered image from the standard packed image [Co_pad][K_pad], K = tap*Ci + ci (3x3, K_pad = 9*Ci, Ci % 64 == 0).
-// block (cot, p, j = tap*cpp + c) of hv*1024 16-byte chunks: chunk (((w*hv + h)*2 + m)*2 + kk)*64 + lane
-//   <- packed[row = cot*128*hv + h*128 + w*32 + m*16 + (lane&15)][k = tap*Ci + (p*cpp + c)*64 + (kk*4 + (lane>>4))*8 .. +8]
-// hv = 1: 128-channel block tiles (pgemm3, pgemm4<.,1>); hv = 2: 256-channel block tiles (pgemm4<.,2>)
-__global__ void frag_pack_kernel(const uint4* __restrict__ packed, uint4* __restrict__ frag, int K_pad, int Ci, int cpp, int hv,
-                                 long long nchunk) {
-  const int npass = Ci / (64 * cpp);
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nchunk; q += (long long)gridDim.x * blockDim.x) {
-    int lane = (int)(q & 63);
-    long long r = q >> 6;
-    int kk = (int)(r & 1); r >>= 1;
-    int m = (int)(r & 1); r >>= 1;
-    int h = (int)(r % hv); r /= hv;
-    int w = (int)(r & 3); r >>= 2;
-    int j = (int)(r % (9 * cpp)); r /= 9 * cpp;
-    int p = (int)(r % npass);
-    int cot = (int)(r / npass);
-    int tap = j / cpp, c = j - tap * cpp;
-    int row = cot * 128 * hv + h * 128 + w * 32 + m * 16 + (lane & 15);
-    int k = tap * Ci + (p * cpp + c) * 64 + (kk * 4 + (lane >> 4)) * 8;
-    frag[q] = packed[((long long)row * K_pad + k) >> 3];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Resident-patch gather-GEMM, persistent, one wave per SIMD with the SIMD's whole 512-register file (MGD_PGEMM=1).
-// Third form of the idea; what the first two (deleted, numbers in DESIGN.md section 3) taught:
-//  * ring form (weights through an LDS-DMA ring, 8 waves in lock step, one barrier per K-step): its parts added up instead
-//    of overlapping - K-loop skeleton 39 us, LDS-DMA 10, fragment reads 20, MFMA 20, epilogue 20 of 115 us on 128->256 at
-//    76x76; every LDS-DMA instruction cost its wave ~100 issue cycles;
-//  * free-running form (fragment-ordered weights from global memory, a fifth wave filling the patch, 32-channel x 128-pixel
-//    wave tiles): 93-99 us.  A 32 x 128 wave tile reads 16 KiB of pixel fragments from LDS per K-step, four waves = 64 KiB
-//    against 512 cycles of MFMA, and five waves per CU cap every wave at 256 registers (spills; their reloads in the
-//    epilogue wait vmcnt(0) and serialise the tile's stores).
-// This form runs FOUR waves per CU and nothing else:
-//  * wave tile 64 channels x 128 pixels (HV = 2; 128 accumulator registers in AGPRs), block tile 256 x 128: per K-step 64
-//    MFMA = 1024 cycles against the same 64 KiB of LDS reads;
-//  * weights from the fragment-ordered image, 8 coalesced 16-byte loads per K-step and lane, two K-steps ahead;
-//  * the four waves fill the next patch buffer themselves (LDS-DMA, issued right after the barrier that opens an item);
-//    loads return in order, so hipcc's counted waits on the weight loads behind them also wait for the DMA - one exposed
-//    L2 round trip per item of 9*CPP K-steps, the price of not having a fifth wave;
-//  * each wave keeps its own copy of the patch-row table (rin), so filling needs no extra barrier; row_dst is double
-//    buffered by tile parity and written one tile ahead;
-//  * the epilogue runs per 128-channel half through the GemmEpilogue of the other forms, in the patch buffer just left.
-// HV = 1 (Co_pad % 256 != 0) keeps 32 x 128 wave tiles.  A wave owns channels h*128 + wave*32 + m*16 of the block tile.
-// Measured (DBG = 2 ablation build, 128->256 at 76x76, batch 16, 80 us whole): patch DMA + barriers alone 17 us, weight +
-// pixel fragment loads +17, MFMA +28 (= 16 cycles each at 1.95 GHz), epilogue +13 (30 when nothing else runs: the 47 MB
-// of output at 1.6 TB/s) - still a sum, one wave per SIMD overlaps little of its own instruction stream.
-template <int CPP, int HV, int DBG = 0>   // DBG: 0 product, 1 cycle stamps, 2 ablation switches
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_pgemm4_kernel(GemmArgs a, Pg3Args g) {
-  constexpr int MT = 2, NT = 8, BNC = 128 * HV, NSTEP = 9 * CPP, BLK = HV * 1024;
-  constexpr bool STAMP = DBG == 1, ABL = DBG == 2;
-  using Epi = GemmEpilogue<4, 1, MT, NT>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int PB = g.pbytes;
-  unsigned char* pbuf = smem;                                      // two patch buffers
-  int* rin = (int*)(smem + 2 * (size_t)PB);                        // [4 waves][2][40]: first pixel of each patch row, or -1
-  long long* row_dst = (long long*)(rin + 320);                    // [2][128]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int* rinw = rin + wave * 80;
-  const int H1 = a.Hs + 1;
-  const int ntiles = a.nblk, nblocks = gridDim.x;
-  const int lb = xcd_remap(blockIdx.x, nblocks);
-  const int mytiles = (ntiles - lb + nblocks - 1) / nblocks;
-  const int npass = g.npass;
-  const int nitems = mytiles * npass;
-  const int pchunk = g.PP8 * 1024;
-
-  auto tile_origin = [&](int T, int& R0, int& c0, int& co0) {
-    const int tc = T % a.tilesC, tp = T / a.tilesC;
-    const int tcol = tp % g.tilesW, trow = tp / g.tilesW;
-    R0 = trow * g.TH; c0 = tcol * g.TW; co0 = tc * BNC;
-  };
-  const int e_r = ((tid >> 4) & 7) * g.NR + (tid & 15) / g.NC, e_c = (tid & 15) % g.NC;   // epilogue pixel of tid < 128
-  // patch-row table of a tile (this wave's copy) and the tile's output rows (tid < 128 = waves 0 and 1, from their copies)
-  auto make_rows = [&](int par, int R0, int c0) {
-    if (lane < g.PH) {
-      const int Rs = R0 + lane - 1;
-      const int n = Rs / H1, h = Rs - n * H1;
-      rinw[par * 40 + lane] = (Rs >= 0 && Rs < g.S && h < a.Hs) ? (n * a.Hs + h) * a.Ws : -1;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (tid < 128) {
-      const int base = rinw[par * 40 + e_r + 1];
-      row_dst[par * 128 + tid] = (base >= 0 && c0 + e_c < a.Ws) ? (long long)(base + c0 + e_c) * a.Co : -1;
-    }
-  };
-  // piece j covers patch pixels 8j .. 8j+7 of a chunk (one 1-KiB LDS-DMA instruction per 64-channel chunk); wave w issues
-  // pieces w, w+4, ...
-  const char* xbase = (const char*)a.src;
-  const void* zero = (const void*)g_zero_page;
-  const unsigned pswz = (unsigned)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);
-  auto issue_patch = [&](int par, int c0, int pass, int buf) {
-    unsigned char* pb = pbuf + (size_t)buf * PB;
-    for (int j = wave; j < g.PP8; j += 4) {
-      const int pix = j * 8 + (lane >> 3);
-      const int pr = pix / g.PW, pc = pix - pr * g.PW;
-      const int base = pr < g.PH ? rinw[par * 40 + pr] : -1, cin = c0 + pc - 1;
-      const bool v = base >= 0 && (unsigned)cin < (unsigned)a.Ws;
-      const size_t off = (size_t)(((long long)(base + cin) * a.Ci) * 2) + pswz + (unsigned)(pass * CPP * 128);
-#pragma unroll
-      for (int c = 0; c < CPP; ++c)
-        glds16(v ? (const void*)(xbase + off + c * 128) : zero, pb + (size_t)c * pchunk + (size_t)j * 1024);
-    }
-  };
-
-  unsigned long long t_begin = 0, t_e = 0, t_b = 0, tq = 0;
-  auto now = [&]() -> unsigned long long {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-  };
-  if (STAMP) t_begin = now();
-  const int fr = lane & 15, fq = lane >> 4;
-  int xpix[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) xpix[n] = (n * g.NR + fr / g.NC) * g.PW + fr % g.NC;
-  const int PW = g.PW;
-  const unsigned pa = lds_addr(pbuf);
-  // block (cot, p, j) of the fragment image starts at chunk ((cot*npass + p)*NSTEP + j) * BLK; this wave: + wave*HV*256
-  const uint4* wlane = (const uint4*)g.wfrag + (size_t)wave * (HV * 256) + lane;
-
-  // ablation switches of the DBG = 2 build only (MGD_DBG bits: 32 no epilogue, 64 no MFMA, 128 no pixel-fragment reads,
-  // 256 no weight-fragment loads); constant false in the product build
-  const bool abl_e = ABL && (a.dbg & 32), abl_m = ABL && (a.dbg & 64), abl_b = ABL && (a.dbg & 128),
-             abl_a = ABL && (a.dbg & 256);
-  f32x4 acc[HV][MT][NT];
-  bf16x8 a0[HV][MT][2], a1[HV][MT][2], a2[HV][MT][2], bX[NT], bY[NT];   // A: three sets, two K-steps ahead
-  auto load_a = [&](bf16x8 (&af)[HV][MT][2], const uint4* wk) {
-#pragma unroll
-    for (int h = 0; h < HV; ++h)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) af[h][m][kk] = __builtin_bit_cast(bf16x8, wk[((h * 2 + m) * 2 + kk) * 64]);
-  };
-  auto load_b = [&](bf16x8 (&bf_)[NT], unsigned pb, int toff, unsigned kkx) {
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int pp = xpix[n] + toff;
-      const unsigned xr = pb + (unsigned)(pp * ROWB + ((fq ^ (pp & 7)) << 4));
-      bf_[n] = *(const __attribute__((address_space(3))) bf16x8*)(size_t)(xr ^ kkx);
-    }
-  };
-  auto mfmas_kk = [&](bf16x8 (&af)[HV][MT][2], bf16x8 (&bf_)[NT], int kk) {
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int h = 0; h < HV; ++h)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          acc[h][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[h][m][kk], bf_[n], acc[h][m][n], 0, 0, 0);
-  };
-
-  int T = lb, R0, c0, co0;
-  tile_origin(T, R0, c0, co0);
-  make_rows(0, R0, c0);
-  issue_patch(0, c0, 0, 0);
-  wait_vmcnt<0>();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                     // patch of item 0 and row_dst[0] are published
-  int item = 0;
-  const uint4* wk = wlane;
-  for (int t = 0; t < mytiles; ++t, T += nblocks) {
-    tile_origin(T, R0, c0, co0);
-    const int par = t & 1;
-    int nR0 = 0, nc0 = 0, nco0 = 0;
-    if (t + 1 < mytiles) {                           // rows of the NEXT tile: read one tile (>= one barrier) later
-      tile_origin(T + nblocks, nR0, nc0, nco0);
-      make_rows(par ^ 1, nR0, nc0);
-    }
-    wk = wlane + (size_t)((T % a.tilesC) * npass) * NSTEP * BLK;
-    load_a(a0, wk);                                  // steps 0 and 1 of the tile
-    load_a(a1, wk + BLK);
-    load_b(bX, pa + (unsigned)((item & 1) * PB), 0, 0u);
-#pragma unroll
-    for (int h = 0; h < HV; ++h)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[h][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int pass = 0; pass < npass; ++pass, ++item) {
-      const unsigned pb = pa + (unsigned)((item & 1) * PB);
-      const unsigned pbn = pa + (unsigned)(((item + 1) & 1) * PB);
-      const bool more_passes = pass + 1 < npass;
-      const bool have_next = item + 1 < nitems;
-      // the other buffer is free (end-of-item barrier, or the barrier that closed the previous tile's epilogue): fill it
-      if (have_next) {
-        if (more_passes) issue_patch(par, c0, pass + 1, (item + 1) & 1);
-        else issue_patch(par ^ 1, nc0, 0, (item + 1) & 1);
-      }
-      const uint4* wnext = wk + NSTEP * BLK;
-#define MGD_PG4_STEP(ca, na2, J)                                                                   \
-      {                                                                                           \
-        constexpr int TAP0 = (J) / CPP, C0 = (J) % CPP;                                           \
-        const unsigned pbc = pb + (unsigned)(C0 * pchunk);                                        \
-        /* opaque per step: otherwise hipcc hoists all fragment addresses out of the tile loop */  \
-        const int toff0 = sgpr((TAP0 / 3) * PW + TAP0 % 3);                                       \
-        if (!abl_a) {                                                                             \
-          if ((J) + 2 < NSTEP) load_a(na2, wk + ((J) + 2) * BLK);                                 \
-          else if (more_passes) load_a(na2, wnext + ((J) + 2 - NSTEP) * BLK);                     \
-        }                                                                                         \
-        if (!abl_b) load_b(bY, pbc, toff0, 64u);                                                  \
-        if (!abl_m) mfmas_kk(ca, bX, 0);                                                          \
-        if ((J) + 1 < NSTEP) {                                                                    \
-          constexpr int J1 = (J) + 1, TAP1 = J1 / CPP, C1 = J1 % CPP;                             \
-          __builtin_amdgcn_sched_barrier(0);                                                      \
-          if (!abl_b) load_b(bX, pb + (unsigned)(C1 * pchunk), sgpr((TAP1 / 3) * PW + TAP1 % 3), 0u); \
-        } else {                                                                                  \
-          __builtin_amdgcn_s_waitcnt(0xC07F);       /* my reads of this patch buffer are done */   \
-          /* my share of the next patch has landed: at least 8*HV weight loads were issued behind the DMA */ \
-          if (have_next) { if (more_passes) wait_vmcnt<8 * HV>(); else wait_vmcnt<0>(); }          \
-          if (STAMP) tq = now();                                                                  \
-          __builtin_amdgcn_s_barrier();             /* end of item: the next patch is there */    \
-          if (STAMP) t_b += now() - tq;                                                           \
-          if (more_passes) load_b(bX, pbn, 0, 0u);                                                \
-        }                                                                                         \
-        if (!abl_m) mfmas_kk(ca, bY, 1);                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-      }
-#define MGD_PG4_TRIPLE(J) MGD_PG4_STEP(a0, a2, J) MGD_PG4_STEP(a1, a0, (J) + 1) MGD_PG4_STEP(a2, a1, (J) + 2)
-      MGD_PG4_TRIPLE(0) MGD_PG4_TRIPLE(3) MGD_PG4_TRIPLE(6)
-      if constexpr (CPP == 2) { MGD_PG4_TRIPLE(9) MGD_PG4_TRIPLE(12) MGD_PG4_TRIPLE(15) }
-#undef MGD_PG4_TRIPLE
-#undef MGD_PG4_STEP
-      wk = wnext;
-    }
-    // ---- epilogue, one 128-channel half at a time, in the patch buffer of the tile's last pass (every wave left it at
-    //      the end-of-item barrier); the other buffer already holds (or is receiving) the next tile's first patch
-    if (STAMP) tq = now();
-    {
-      unsigned char* el = pbuf + (size_t)((item - 1) & 1) * PB;
-      const long long* rd = row_dst + par * 128;
-#pragma unroll
-      for (int h = 0; h < HV; ++h) {
-        if (abl_e) break;
-        Epi epi;
-        epi.prefetch(a, rd, co0 + h * 128, tid, false);
-        epi.template run<false, false>(a, acc[h], el, rd, co0 + h * 128, tid);
-        lds_barrier();                              // the LDS tile (and, after the last half, the buffer) is free again
-      }
-    }
-    if (STAMP) t_e += now() - tq;
-  }
-  if (STAMP && a.stamps && lane == 0) {
-    const unsigned long long t_end = now();
-    atomicAdd(a.stamps + 0, 0ull); atomicAdd(a.stamps + 1, 0ull); atomicAdd(a.stamps + 2, t_b);
-    atomicAdd(a.stamps + 3, (t_end - t_begin) - t_b - t_e); atomicAdd(a.stamps + 4, t_e);
-    atomicAdd(a.stamps + 5, (unsigned long long)mytiles);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1478,25 +1343,26 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
     x_j[i] = rem - x_i[i] * a.Wg;
   }
 
-  // stages the NEXT K-step (steps are issued in order, each exactly once) into ring slot buf
-  auto issue_o = [&](int buf) {
-    unsigned char* ob = smem + buf * STAGE;
+  // Staging the NEXT K-step (steps go out in order, each exactly once) is split in two: prep() derives the eight source
+  // addresses and advances the carried state - plain VALU work, placed behind the first MFMAs of the PREVIOUS step, where
+  // it runs in the shadow of the matrix pipe - and fire() is the eight LDS-DMA instructions alone, right after the barrier:
+  // with a two-deep ring the DMA round trip is the step's critical path, and nothing may sit between barrier and issue.
+  const void* og[OCH];
+  const void* xg[ICH];
+  auto prep = [&]() {
 #pragma unroll
     for (int i = 0; i < OCH; ++i) {
       const bool v = o_p[i] < pend && o_cb[i] >= 0;
-      glds16(v ? (const void*)(dyb + o_off[i]) : zero, ob + (i * 4 + wave) * 1024);
+      og[i] = v ? (const void*)(dyb + o_off[i]) : zero;
       o_p[i] += 64;
       o_off[i] += (long long)Co * 128;
     }
-  };
-  auto issue_x = [&](int buf) {
-    unsigned char* ib = smem + buf * STAGE + 64 * RBO;
 #pragma unroll
     for (int i = 0; i < ICH; ++i) {
       const int hs = x_i[i] * sst + dh, ws = x_j[i] * sst + dw;
       const bool v = x_p[i] < pend && x_cb[i] >= 0 && (unsigned)hs < (unsigned)Hs && (unsigned)ws < (unsigned)Ws;
       const int lin = (x_n[i] * Hs + hs) * Ws + ws;
-      glds16(v ? (const void*)(srcb + (long long)lin * (Ci * 2) + x_cb[i]) : zero, ib + (i * 4 + wave) * 1024);
+      xg[i] = v ? (const void*)(srcb + (long long)lin * (Ci * 2) + x_cb[i]) : zero;
       x_p[i] += 64;
       x_j[i] += r64;
       x_i[i] += q64;
@@ -1510,6 +1376,14 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
       }
     }
   };
+  auto fire = [&](int buf) {
+    unsigned char* ob = smem + buf * STAGE;
+    unsigned char* ib = ob + 64 * RBO;
+#pragma unroll
+    for (int i = 0; i < OCH; ++i) glds16(og[i], ob + (i * 4 + wave) * 1024);
+#pragma unroll
+    for (int i = 0; i < ICH; ++i) glds16(xg[i], ib + (i * 4 + wave) * 1024);
+  };
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -1517,7 +1391,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) { issue_o(0); issue_x(0); }
+  prep();
+  if (nk > 0) fire(0);
+  prep();                   // addresses of step 1
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
   // fragment read offsets inside a stage: MFMA k index = pixel row kk*32 + 8g + qq (+4 for the upper half)
   int o_rd[2][2][MT], i_rd[2][2][NT];
@@ -1571,13 +1447,12 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
         }
       }
     };
-    // the next stage goes out FIRST: with a two-deep ring its round trip is the step's critical path (issuing the input
-    // half behind the first MFMAs instead cost 75 %)
-    if (more) { issue_o((ks + 1) & 1); issue_x((ks + 1) & 1); }
+    if (more) fire((ks + 1) & 1);
     read_half(0);
     wait_lgkm_dyn(0);
     read_half(1);          // in flight under the MFMAs of the first half
     mfma_half(0);
+    prep();                // addresses of step ks + 2
     wait_lgkm_dyn(0);
     mfma_half(1);
   }
@@ -2255,10 +2130,25 @@ struct PackJob {
   long long begin;   // first flat element index of this job
 };
 
+// Layout of a packed image [rows_pad][K_pad]:
+//  * rows_pad % 128 != 0 (64- and 32-row tiles, patch kernels): row-major;
+//  * rows_pad % 128 == 0: MFMA-FRAGMENT ORDER.  Per (128-row tile cot, 64-deep K-step ks) one 16-KiB block of 1024 16-byte
+//    chunks, chunk ((wcm*2 + kk)*64 + lane) = row cot*128 + wcm*16 + (lane & 15), columns ks*64 + (kk*4 + (lane >> 4))*8 .. +8
+//    (wcm = 16-row group 0..7, kk = 32-deep half).  A wave's A operand of a K-step is then plain coalesced 16-byte global
+//    loads (conv_gemm8_kernel) or, staged through LDS (conv_gemm6_kernel), a linear copy read back conflict-free.
+__device__ __forceinline__ long long packed_elem(int r, int k, int rows_pad, int K_pad) {
+  if (rows_pad & 127) return (long long)r * K_pad + k;
+  const int nk = K_pad >> 6;
+  const int cot = r >> 7, wcm = (r >> 4) & 7, fr = r & 15;
+  const int ks = k >> 6, kk = (k >> 5) & 1, fq = (k >> 3) & 3;
+  return ((((long long)cot * nk + ks) * 16 + wcm * 2 + kk) * 64 + fq * 16 + fr) * 8 + (k & 7);
+}
+
 // One block iteration = one 32-row x 64-column tile of one packed image (output rows r0.., columns t*cin + c0..); the
 // tile is read along the source's contiguous index (ci for forward images, the OUTPUT-row index for transposed /
-// data-gradient images) and transposed through LDS when needed, so both sides are coalesced: 128-byte source rows,
-// 128-byte bf16 output rows (two columns per thread).  Only the valid region is written: the zero padding of the
+// data-gradient images) and goes through LDS, so both sides are coalesced: 128-byte source rows, and on the output side
+// 128-byte bf16 rows (row-major images, two columns per thread) or, in fragment order, one 16-byte chunk per thread with
+// 16 consecutive rows = 256 contiguous bytes per 16 lanes.  Only the valid region is written: the zero padding of the
 // images is written once at allocation and never changes.  `begin` of a job = index of its first tile.
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs, long long total) {
   __shared__ float tile[64][33];
@@ -2279,6 +2169,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restri
     const int r0 = rt * 32, c0 = ct * 64;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const bool even = !((J.Ci | J.Co) & 1) && !(((uintptr_t)J.w) & 7);   // paired 4-byte stores / 8-byte loads are aligned
+    const bool frag = !(J.rows_pad & 127);
     if (J.transpose) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -2286,6 +2177,41 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restri
         tile[ty + 8 * j][tx] = (c < cin && r < rows) ? J.w[((long long)c * J.T + st) * J.Ci + r] : 0.f;
       }
       __syncthreads();
+    } else if (frag) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int r = r0 + ty + 8 * j, c = c0 + 2 * tx;
+        float v0 = 0.f, v1 = 0.f;
+        if (r < rows && c < cin) {
+          const float* wsrc = J.w + ((long long)r * J.T + st) * J.Ci + c;
+          if (even) { float2 v = *(const float2*)wsrc; v0 = v.x; v1 = v.y; }
+          else { v0 = wsrc[0]; if (c + 1 < cin) v1 = wsrc[1]; }
+        }
+        tile[2 * tx][ty + 8 * j] = v0;
+        tile[2 * tx + 1][ty + 8 * j] = v1;
+      }
+      __syncthreads();
+    }
+    if (frag) {
+      if (!(cin & 7)) {
+        // one 16-byte chunk per thread: rows r0 + (tid & 31), columns c0 + 8*(tid >> 5) .. +8
+        const int rl = threadIdx.x & 31, q = threadIdx.x >> 5;
+        const int r = r0 + rl, c = c0 + q * 8;
+        if (r < rows && c < cin) {
+          float f[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = tile[q * 8 + j][rl];
+          *(uint4*)(J.out + packed_elem(r, t * cin + c, J.rows_pad, J.K_pad)) = pack8(f);
+        }
+      } else {                                        // channel counts that are no multiple of 8 (the 255-channel heads)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = r0 + tx, c = c0 + ty + 8 * j;
+          if (r < rows && c < cin) J.out[packed_elem(r, t * cin + c, J.rows_pad, J.K_pad)] = f2bf(tile[ty + 8 * j][tx]);
+        }
+      }
+      __syncthreads();
+    } else if (J.transpose) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int r = r0 + ty + 8 * j, c = c0 + 2 * tx;
@@ -2334,7 +2260,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, bf16_t* __restr
     int st = (int)((srccode >> (4 * t)) & 15);
     v = transpose ? w[((long long)c * T + st) * Ci + r] : w[((long long)r * T + st) * Ci + c];
   }
-  out[i] = f2bf(v);
+  out[packed_elem(r, k, rows_pad, K_pad)] = f2bf(v);
 }
 
 unsigned long long make_tapcode(int ntaps, const int32_t* dh, const int32_t* dw, bool* ok) {
@@ -2368,71 +2294,6 @@ int launch_gemm2(GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
-
-int pgemm_mode() {
-  static int pgemm = -1;
-  if (pgemm < 0) { const char* e = getenv("MGD_PGEMM"); pgemm = e ? atoi(e) : 0; }
-  return pgemm;
-}
-// 256-channel block tiles (two 128-channel halves per wave) when the padded channel count allows; the fragment image
-// (mgd_frag_pack) and the kernel (mgd_conv_gather_gemm) agree through this one function
-int pgemm_halves(int Co_pad) { return Co_pad % 256 == 0 ? 2 : 1; }
-
-template <int CPP, int HV>
-int launch_pgemm4(GemmArgs& a, const PgArgs& pg, const void* wfrag, hipStream_t st) {
-  Pg3Args g;
-  g.wfrag = (const bf16_t*)wfrag;
-  g.NC = pg.NC; g.NR = pg.NR; g.TH = pg.TH; g.TW = pg.TW; g.PW = pg.PW; g.PP = pg.PP; g.PP8 = pg.PP8; g.PH = pg.TH + 2;
-  g.S = pg.S; g.tilesW = pg.tilesW; g.tilesR = pg.tilesR; g.npass = pg.nch / CPP;
-  const int need = 128 * (128 * 2 + 16) + 4 * 2 * 128 * 4 + 1024;
-  g.pbytes = CPP * g.PP8 * 1024 > need ? CPP * g.PP8 * 1024 : need;
-  a.tilesC = a.Co_pad / (128 * HV);
-  a.nblk = a.tilesC * g.tilesR * g.tilesW;
-  size_t lds = 2 * (size_t)g.pbytes + 320 * 4 + 2 * 128 * 8;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_pgemm4_kernel<CPP, HV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_pgemm4_kernel<CPP, HV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_pgemm4_kernel<CPP, HV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
-  int grid = a.nblk < 256 ? a.nblk : 256;
-  if (a.dbg & 2) {
-    (void)hipGetSymbolAddress((void**)&a.stamps, HIP_SYMBOL(g_stamps));
-    hipLaunchKernelGGL((conv_pgemm4_kernel<CPP, HV, 1>), dim3(grid), dim3(256), lds, st, a, g);
-  } else if (a.dbg & 0x1E0) {
-    hipLaunchKernelGGL((conv_pgemm4_kernel<CPP, HV, 2>), dim3(grid), dim3(256), lds, st, a, g);
-  } else {
-    hipLaunchKernelGGL((conv_pgemm4_kernel<CPP, HV, 0>), dim3(grid), dim3(256), lds, st, a, g);
-  }
-  return 0;
-}
-
-// geometry of the resident-patch form for an H x W map; false if the layer does not qualify
-bool pgemm_geometry(const mgd_conv_desc* d, PgArgs* g) {
-  bool std9 = d->ntaps == 9 && d->in_stride == 1 && d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 &&
-              d->Hs == d->Hg && d->Ws == d->Wg && d->Hd == d->Hg && d->Wd == d->Wg && d->Ci % 64 == 0 && d->Ci >= 64 &&
-              d->K_pad == 9 * d->Ci && d->Co_pad % 128 == 0 && !d->dst_f32 && d->Wg >= 4 && d->Hg >= 2;
-  for (int t = 0; t < 9 && std9; ++t) std9 = d->dh[t] == t / 3 - 1 && d->dw[t] == t % 3 - 1;
-  if (!std9) return false;
-  int best = 16;
-  double beste = 0;
-  for (int nc = 16; nc >= 4; nc >>= 1) {
-    double e = (double)d->Wg / ((double)cdiv(d->Wg, nc) * nc);
-    if (e > beste + 1e-9) { beste = e; best = nc; }
-  }
-  g->NC = best; g->NR = 16 / best; g->TH = 8 * g->NR; g->TW = best;
-  g->PW = g->TW + 2; g->PP = g->PW * (g->TH + 2); g->PP8 = (g->PP + 7) / 8;
-  long long S = (long long)d->N * (d->Hg + 1) - 1;
-  if (S >= (1ll << 30)) return false;
-  g->S = (int)S;
-  g->tilesW = cdiv(d->Wg, g->TW); g->tilesR = cdiv(S, g->TH);
-  g->nch = d->Ci / 64; g->cpp = g->nch < 4 ? g->nch : 4;
-  if (g->nch % g->cpp) return false;
-  g->npass = g->nch / g->cpp;
-  g->pbytes = 0;
-  return g->PP8 <= 26 && g->TH + 2 <= 40 && (g->nch == 1 || g->nch % 2 == 0);
-}
 
 template <int WC, int WP, int MT, int NT, int NS>
 int launch_gemm6(GemmArgs& a, hipStream_t st) {
@@ -2477,18 +2338,6 @@ int launch_patch(GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
-int launch_gemm2_stamped(GemmArgs& a, hipStream_t st) {
-  constexpr int BNC = 128, BMP = 128, NST = 2;
-  a.tilesC = a.Co_pad / BNC;
-  a.nblk = a.tilesC * cdiv(a.M, BMP);
-  size_t ring = (size_t)NST * (BNC + BMP) * ROWB, epi = (size_t)BMP * (BNC * 4 + 16);
-  ring = (ring > epi ? ring : epi) + (size_t)BMP * 8 + 1024;
-  auto k = conv_gemm2_kernel<2, 2, 4, 4, 2, true>;
-  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipGetSymbolAddress((void**)&a.stamps, HIP_SYMBOL(g_stamps));
-  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), ring, st, a);
-  return 0;
-}
 
 template <int WC, int WI, int MT, int NT>
 int launch_wgrad(WgradArgs& a, hipStream_t st) {
@@ -2623,58 +2472,35 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
       return MGD_OK;
     }
   }
-  // persistent resident-patch form for the 3x3 stride-1 layers with Ci >= 64 (forward and stride-1 data gradient):
-  // opt-in (MGD_PGEMM=1; needs the fragment-ordered weight image, mgd_frag_pack), see DESIGN.md section 3
-  {
-    const int pgemm = pgemm_mode();
-    PgArgs g;
-    if (variant == 3 && pgemm != 0 && d->wfrag && pgemm_geometry(d, &g) && g.TH + 2 <= 40) {
-      const bool c2 = g.nch % 2 == 0;
-      if (pgemm_halves(d->Co_pad) == 2) { if (c2) launch_pgemm4<2, 2>(a, g, d->wfrag, st); else launch_pgemm4<1, 2>(a, g, d->wfrag, st); }
-      else { if (c2) launch_pgemm4<2, 1>(a, g, d->wfrag, st); else launch_pgemm4<1, 1>(a, g, d->wfrag, st); }
-      MGD_CHECK_LAUNCH("conv_gather_gemm(large-register resident patch)");
+  // 128-channel tiles (the packed image is in fragment order, packed_elem):
+  //  * launches that do not fill the CUs once and have a K-loop worth pipelining: producer/consumer form - one deep-ring
+  //    block per CU hides the latency of a long K-loop better than a third of the CUs' worth of barrier-synchronous blocks
+  //    (1024->512 at 19x19, 184 tiles: 66 us against 108);
+  //  * everything else: weights straight from global memory, three blocks per CU.
+  if (d->Co_pad % 128 == 0) {
+    static int pc = -1;
+    if (pc < 0) { const char* e = getenv("MGD_PRODCONS"); pc = e ? atoi(e) : 1; }
+    const long long nblk128 = (long long)(d->Co_pad / 128) * cdiv(a.M, 128);
+    if (nk >= 4 && !d->dst_f32 && (variant == 9 || (pc && nblk128 <= 256))) {
+      static int ns6 = -1;
+      if (ns6 < 0) { const char* e = getenv("MGD_PC_STAGES"); ns6 = e ? atoi(e) : 4; }   // 4 stages: equal to 3 alone, 0.2 % faster inside the step (latency under the side stream)
+      if (ns6 == 4) launch_gemm6<2, 2, 4, 4, 4>(a, st); else launch_gemm6<2, 2, 4, 4, 3>(a, st);
+      MGD_CHECK_LAUNCH("conv_gather_gemm(producer/consumer)");
       return MGD_OK;
     }
-  }
-  // producer/consumer form: wins when the launch has few tiles per CU or long K-loops (its single block per CU leaves
-  // prologue and epilogue exposed, which two barrier-synchronous blocks per CU hide on the short-K, many-tile layers)
-  static int pc = -1;
-  if (pc < 0) { const char* e = getenv("MGD_PRODCONS"); pc = e ? atoi(e) : 1; }
-  const long long nblk128 = (long long)(d->Co_pad / 128) * cdiv(a.M, 128);
-  if (d->Co_pad % 128 == 0 && nk >= 4 && !d->dst_f32 &&
-      (variant == 9 || (variant == 3 && pc && (nblk128 <= 256 || (nblk128 <= 768 && nk >= 32))))) {
-    static int ns6 = -1;
-    if (ns6 < 0) { const char* e = getenv("MGD_PC_STAGES"); ns6 = e ? atoi(e) : 4; }   // 4 stages: equal to 3 alone, 0.2 % faster inside the step (latency under the side stream)
-    if (ns6 == 4) launch_gemm6<2, 2, 4, 4, 4>(a, st); else launch_gemm6<2, 2, 4, 4, 3>(a, st);
-    MGD_CHECK_LAUNCH("conv_gather_gemm(producer/consumer)");
+    launch_gemm8<2, 3>(a, st);
+    MGD_CHECK_LAUNCH("conv_gather_gemm(global weight fragments)");
     return MGD_OK;
   }
   {
     const bool deep = (variant == 2) ? nk >= 6 : (variant == 4);
-    if (d->Co_pad % 128 == 0) {
-      if (deep) launch_gemm2<2, 2, 4, 4, 4>(a, st);
-      else if (a.dbg & 2) launch_gemm2_stamped(a, st);
-      else launch_gemm2<2, 2, 4, 4, 2>(a, st);
-    } else if (d->Co_pad % 64 == 0) {
+    if (d->Co_pad % 64 == 0) {
       if (deep) launch_gemm2<1, 4, 4, 2, 4>(a, st); else launch_gemm2<1, 4, 4, 2, 2>(a, st);
     } else {
       if (deep) launch_gemm2<1, 4, 2, 2, 4>(a, st); else launch_gemm2<1, 4, 2, 2, 2>(a, st);
     }
   }
   MGD_CHECK_LAUNCH("conv_gather_gemm");
-  return MGD_OK;
-}
-
-extern "C" int mgd_frag_pack(const void* packed, void* frag, int Co_pad, int K_pad, int Ci, void* stream) {
-  MGD_REQUIRE(packed && frag, "frag_pack: null pointer");
-  MGD_REQUIRE(Co_pad % 128 == 0 && Ci % 64 == 0 && K_pad == 9 * Ci, "frag_pack: needs Co_pad %% 128 == 0, Ci %% 64 == 0, K_pad == 9*Ci");
-  const int cpp = (Ci / 64) % 2 == 0 ? 2 : 1;
-  long long nchunk = (long long)Co_pad * K_pad / 8;
-  long long g = (nchunk + 255) / 256;
-  if (g > 256 * 16) g = 256 * 16;
-  hipLaunchKernelGGL(frag_pack_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const uint4*)packed, (uint4*)frag, K_pad,
-                     Ci, cpp, pgemm_halves(Co_pad), nchunk);
-  MGD_CHECK_LAUNCH("frag_pack");
   return MGD_OK;
 }
 

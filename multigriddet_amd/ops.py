@@ -31,7 +31,7 @@ def _launch_gemm(d, what):
     e1.record()
     variant = "gemm128" if d.Co_pad % 128 == 0 else ("gemm64" if d.Co_pad % 64 == 0 else "gemm32")
     nb, nk = (d.Co_pad // 128) * -(-(d.N * d.Hg * d.Wg) // 128), d.K_pad // 64
-    if variant == "gemm128" and not d.dst_f32 and nk >= 4 and (nb <= 256 or (nb <= 768 and nk >= 32)):
+    if variant == "gemm128" and not d.dst_f32 and nk >= 4 and nb <= 256:
         variant = "gemm128pc"        # dispatched to the producer/consumer kernel (same rule as conv.hip)
     PROFILE.append((e0, e1, 2.0 * d.N * d.Hg * d.Wg * d.ntaps * d.Ci * d.Co, variant, what))
 
@@ -90,24 +90,6 @@ class PackedConv:
                         self.dgrad.append((torch.zeros(cp, kp, dtype=torch.bfloat16, device=device), kp, cp,
                                            [t[2] for t in tp], (ph, pw, tp)))
 
-    def _frag_ok(self, rows_pad, cin):
-        return _PGEMM != 0 and self.k == 3 and self.s == 1 and rows_pad % 128 == 0 and cin % 64 == 0
-
-    def refresh_frag(self):
-        """Fragment-ordered twins of the 3x3 stride-1 images (MGD_PGEMM=1)."""
-        lib = L.load()
-        if self._frag_ok(self.fwd_copad, self.ci):
-            if getattr(self, "fwd_frag", None) is None:
-                self.fwd_frag = torch.empty_like(self.fwd)
-            L.check(lib.mgd_frag_pack(L.ptr(self.fwd), L.ptr(self.fwd_frag), self.fwd_copad, self.fwd_kpad, self.ci,
-                                      L.stream_ptr()), "frag_pack")
-        if self.dgrad and self.s == 1:
-            img, kp, cp, _, _ = self.dgrad[0]
-            if self._frag_ok(cp, self.co) and kp == 9 * self.co:
-                if getattr(self, "dgrad_frag", None) is None:
-                    self.dgrad_frag = torch.empty_like(img)
-                L.check(lib.mgd_frag_pack(L.ptr(img), L.ptr(self.dgrad_frag), cp, kp, self.co, L.stream_ptr()), "frag_pack")
-
     def refresh_fwd(self, w):
         """w: fp32 [Co, T, Ci] -> rewrite the forward image only."""
         src = (C.c_int32 * 9)(*range(self.T), *([0] * (9 - self.T)))
@@ -124,8 +106,6 @@ class PackedConv:
             src = (C.c_int32 * 9)(*st, *([0] * (9 - len(st))))
             L.check(lib.mgd_pack_weights(L.ptr(w), L.ptr(img), self.co, self.T, self.ci_master, 1, len(st), src, cp, kp,
                                          L.stream_ptr()), "pack dgrad")
-        if _PGEMM != 0:
-            self.refresh_frag()
 
 
 class PackBatch:
@@ -159,9 +139,6 @@ class PackBatch:
     def run(self):
         L.check(L.load().mgd_pack_weights_batch(L.ptr(self.table), self.n, C.c_int64(self.total), L.stream_ptr()),
                 "pack_batch")
-        if _PGEMM != 0:
-            for pk in self.pks:
-                pk.refresh_frag()
 
 
 def stem_im2col(image, out=None):
@@ -173,10 +150,9 @@ def stem_im2col(image, out=None):
 
 
 def _desc(src, wpk, dst, N, Hs, Ws, Ci, Hg, Wg, Hd, Wd, Co, in_stride, out_stride, off, dh, dw, K_pad, Co_pad,
-          bias=None, addend=None, stats=None, dst_f32=False, bnred=None, act_slope=0.0, wfrag=None):
+          bias=None, addend=None, stats=None, dst_f32=False, bnred=None, act_slope=0.0):
     d = L.ConvDesc()
     d.act_slope = act_slope
-    d.wfrag = wfrag.data_ptr() if wfrag is not None else None
     d.src, d.wpk, d.dst = src.data_ptr(), wpk.data_ptr(), dst.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.addend = addend.data_ptr() if addend is not None else None
@@ -206,8 +182,7 @@ def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False, act_slope=0.
         out = torch.empty(N, Ho, Wo, pk.co, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     dh, dw = taps_fwd(pk.k)
     d = _desc(x, pk.fwd if wimg is None else wimg, out, N, H, W, Ci, Ho, Wo, Ho, Wo, pk.co, pk.s, 1, (0, 0), dh, dw,
-              pk.fwd_kpad, pk.fwd_copad, bias=bias, stats=stats, dst_f32=out_f32, act_slope=act_slope, addend=addend,
-              wfrag=getattr(pk, "fwd_frag", None) if wimg is None else None)
+              pk.fwd_kpad, pk.fwd_copad, bias=bias, stats=stats, dst_f32=out_f32, act_slope=act_slope, addend=addend)
     _launch_gemm(d, "conv_fwd")
     return out
 
@@ -225,7 +200,7 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
         img, kp, cp, _, _ = pk.dgrad[0]
         dh, dw = taps_fwd(pk.k)
         d = _desc(dy, img, out, N, Ho, Wo, Co, H, W, H, W, pk.ci, 1, 1, (0, 0), dh, dw, kp, cp, addend=addend,
-                  bnred=bnred, wfrag=getattr(pk, "dgrad_frag", None))
+                  bnred=bnred)
         _launch_gemm(d, "conv_dgrad")
     elif pk.k == 3 and pk.ci == 32 and pk.co == 64 and _S2_PATCH:
         # the first down-sampling layer: all four parity classes in one patch-form launch (dy read once)
@@ -252,7 +227,6 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
 
 import os as _os
 _S2_PATCH = _os.environ.get("MGD_S2_PATCH", "1") != "0"
-_PGEMM = int(_os.environ.get("MGD_PGEMM", "0"))
 _WGRAD_BLOCKS = int(_os.environ.get("MGD_WGRAD_BLOCKS", "512"))
 
 

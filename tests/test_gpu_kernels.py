@@ -942,49 +942,3 @@ def test_per_scale_nms_option_vs_oracle(dev):
         assert differs
     with pytest.raises(ValueError):
         dec.postprocess_batch(heads, shapes, nms_method="soft", per_scale_nms=True)
-
-
-def test_persistent_resident_patch_gemm_opt_in(dev):
-    """MGD_PGEMM=1 (read once per process, hence a child process): the persistent resident-patch form of the 3x3 stride-1
-    gather-GEMM (conv_pgemm4_kernel: input patch staged once per pass, fragment-ordered weights from mgd_frag_pack, 256- and
-    128-channel block tiles, one or two 64-channel chunks per pass) must agree with the default kernels - forward with
-    BatchNorm statistics, and the data gradient with addend - on every tile geometry (1x16, 2x8 and 4x4 n-tiles; one to
-    eight passes; maps smaller than a tile; tiles spanning images)."""
-    import subprocess, sys
-    code = r"""
-import sys, torch
-sys.path.insert(0, %r)
-from multigriddet_amd import ops
-dev = torch.device('cuda:0')
-cases = [(2, 20, 20, 64, 128), (3, 5, 7, 64, 128), (2, 19, 19, 512, 1024), (2, 38, 38, 256, 512), (2, 76, 76, 128, 256),
-         (1, 21, 37, 256, 128), (16, 19, 19, 256, 512), (2, 9, 9, 64, 256), (1, 16, 16, 192, 384)]
-g = torch.Generator().manual_seed(3)
-out = {}
-for (N, H, W, Ci, Co) in cases:
-    x = torch.randn(N, H, W, Ci, generator=g).to(torch.bfloat16).to(dev)
-    w = (torch.randn(Co, 9, Ci, generator=g) / (3 * Ci ** 0.5)).to(dev)
-    dy = torch.randn(N, H, W, Co, generator=g).to(torch.bfloat16).to(dev)
-    add = torch.randn(N, H, W, Ci, generator=g).to(torch.bfloat16).to(dev)
-    pk = ops.PackedConv(Co, Ci, 3, 1, dev); pk.refresh(w)
-    st = torch.zeros(ops.STATS_REPLICAS, 2, Co, device=dev)
-    y = ops.conv_fwd(x, pk, stats=st)
-    dx = ops.conv_dgrad(dy, pk, (H, W), addend=add)
-    torch.cuda.synchronize()
-    out[(N, H, W, Ci, Co)] = (y.float().cpu(), st.sum(0).cpu(), dx.float().cpu())
-torch.save(out, sys.argv[1])
-""" % ROOT
-    import tempfile
-    from conftest import ROOT as _R
-    res = {}
-    with tempfile.TemporaryDirectory() as tmp:
-        for tag, env in (("default", {}), ("pgemm", {"MGD_PGEMM": "1"})):
-            path = os.path.join(tmp, tag + ".pt")
-            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True)
-            assert r.returncode == 0, r.stdout + r.stderr
-            res[tag] = torch.load(path, weights_only=True)
-    for k, (y0, s0, d0) in res["default"].items():
-        y1, s1, d1 = res["pgemm"][k]
-        assert (y1 - y0).abs().max().item() <= 0.02 * y0.abs().max().item() + 1e-3, k     # bf16 rounding of fp32 sums in another order
-        np.testing.assert_allclose(s1[0].numpy(), s0[0].numpy(), rtol=5e-3, atol=0.3)
-        np.testing.assert_allclose(s1[1].numpy(), s0[1].numpy(), rtol=5e-3, atol=0.3)
-        assert (d1 - d0).abs().max().item() <= 0.02 * d0.abs().max().item() + 1e-3, k

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Debug helper: forward conv of the resident-patch kernel against torch fp32 on several shapes; prints where errors sit."""
+"""Debug helper: forward conv (3x3, stride 1) against torch fp32 on several shapes; prints where errors sit."""
 import os, sys
 import torch, torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
