@@ -138,7 +138,7 @@ def infer_bench(dev, size, steps=20, warmup=3):
             "data": "synthetic, random-init weights, moving BN statistics", "runs": runs}
 
 
-def pmc_traffic(prefix="conv_wgrad2_kernel<2, 2, 4, 4>"):
+def pmc_traffic(prefix="conv_wgrad2_kernel<2, 2, 4, 2>"):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (collected in separate
     rocprofv3 --pmc passes of this same command; FETCH_SIZE x2 on gfx950 + WRITE_SIZE); (None, reason) if absent."""
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
@@ -236,9 +236,9 @@ def main():
         names = {"gemm128": "conv_gemm8_kernel<2,3> (128x128-tile bf16 MFMA gather-GEMM, weight fragments from global memory, "
                             "pixel tile through an LDS-DMA ring, three blocks per CU: 3x3/1x1 conv forward + data gradient)",
                  "gemm128pc": "conv_gemm6_kernel<2,2,4,4,4> (128x128-tile bf16 MFMA gather-GEMM, producer/consumer waves)",
-                 "wgrad128": "conv_wgrad2_kernel<2,2,4,4> (128x128-tile bf16 MFMA weight gradient, per-tap blocks, split-K)"}
+                 "wgrad128": "conv_wgrad2_kernel<2,2,4,2> (128x64-tile bf16 MFMA weight gradient, per-tap blocks, split-K, three blocks per CU)"}
         pmc_keys = {"gemm128": "conv_gemm8_kernel<2, 3>", "gemm128pc": "conv_gemm6_kernel<2, 2, 4, 4",
-                    "wgrad128": "conv_wgrad2_kernel<2, 2, 4, 4>"}
+                    "wgrad128": "conv_wgrad2_kernel<2, 2, 4, 2>"}
         step_ms = dt * 1e3 / args.steps
 
         def summarise(tag, only=None):

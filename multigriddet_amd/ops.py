@@ -227,21 +227,26 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
 
 import os as _os
 _S2_PATCH = _os.environ.get("MGD_S2_PATCH", "1") != "0"
-_WGRAD_BLOCKS = int(_os.environ.get("MGD_WGRAD_BLOCKS", "512"))
+_WGRAD_BLOCKS = int(_os.environ.get("MGD_WGRAD_BLOCKS", "0"))      # 0: by tile shape
+_WGRAD_TILE = int(_os.environ.get("MGD_WGRAD_TILE", "1"))         # must match the library (same variable)
 
 
 def wgrad_splits(P, co, ci, T, target_blocks=None):
     """Split-K factor of the per-tap weight-gradient kernel.  Cost model fitted to tools/bench_wgrad_splits.py (it
-    reproduces the measured optimum on every layer of the graph): blocks = tiles * splits run two per CU, so
-    ceil(blocks / 512) rounds of K-steps at 1.63 us each, plus the fp32-atomic epilogue, which is bound by the
-    memory-side atomic rate (64 KB per block at 1.3 TB/s = 0.05 us per block, not overlapped)."""
+    reproduces the measured optimum on the layers of the graph to within a few percent): blocks = tiles * splits run three
+    per CU (128 x 64 tiles, 48 KB of LDS each; two per CU for the other tile shapes), so ceil(blocks / slots) rounds of
+    K-steps at 1.63 us each, plus the fp32-atomic epilogue, which is bound by the memory-side atomic rate (64 KB per
+    128 x 128 block at 1.3 TB/s = 0.05 us per block, not overlapped)."""
     bco = 128 if co > 64 else (64 if co > 32 else 32)
     bci = 128 if ci > 64 else (64 if ci > 32 else 32)
+    big = co > 64 and ci > 64
+    if big and _WGRAD_TILE:
+        bco, bci = (128, 64) if _WGRAD_TILE == 1 else (64, 128)
     tiles = -(-co // bco) * -(-ci // bci) * T
     if target_blocks or T == 1:        # 1x1: ~1 block per CU, measured (short blocks, the epilogue dominates)
-        target_blocks = target_blocks or _WGRAD_BLOCKS // 2
+        target_blocks = target_blocks or 256
         return max(1, min(int(target_blocks / tiles + 0.5), -(-P // 256)))
-    slots = _WGRAD_BLOCKS
+    slots = _WGRAD_BLOCKS if _WGRAD_BLOCKS else (768 if (big and _WGRAD_TILE == 1) else 512)
     atom = 0.05 * (bco * bci) / (128.0 * 128.0)
     best, best_cost = 1, None
     for sp in range(1, max(1, min(256, P // 256)) + 1):
