@@ -788,10 +788,10 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
 // little LDS (40 KB) and so few registers (165) that THREE blocks share a CU (three waves per SIMD).  Measured against the
 // form with both operands in the ring (conv_gemm2_kernel<2,2,4,4,2>, since removed), 608x608 batch 16: 128->256 at 76x76
 // 79 -> 68 us, 256->512 at 38x38 74 -> 64 us, 64->128 at 152x152 103 -> 85 us; a deeper ring (NST = 3, 4) is not faster.
-// Tile 128 x 128, 4 waves of 64 x 64, epilogue = GemmEpilogue.
-template <int NST, int WPE>
+// Tile 128 x 128, 4 waves of 32 channels x 128 pixels (WC = 4) or 64 x 64 (WC = 2), epilogue = GemmEpilogue.
+template <int NST, int WPE, bool ABL = false, int WC = 2>   // ABL: ablation build (MGD_DBG bits switch parts of the loop off); WC: waves along the channels
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void conv_gemm8_kernel(GemmArgs a) {
-  constexpr int WC = 2, WP = 2, MT = 4, NT = 4, BNC = 128, BMP = 128, NTHR = 256;
+  constexpr int WP = 4 / WC, MT = 8 / WC, NT = 8 / WP, BNC = 128, BMP = 128, NTHR = 256;
   constexpr int RPR = NTHR / 8, XCH = BMP / RPR;          // 32 rows per LDS-DMA round, 4 pixel pieces per wave and stage
   constexpr int STAGE = BMP * ROWB;
   using Epi = GemmEpilogue<WC, WP, MT, NT>;
@@ -804,7 +804,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   const int L = xcd_remap(blockIdx.x, a.nblk);
   const int tc = L % a.tilesC, tp = L / a.tilesC;
   const int co0 = tc * BNC, pix0 = tp * BMP;
-  const int nk = a.K_pad / BK;
+  if (ABL && (a.dbg & 1024)) return;                  // dispatch cost alone
+  const int nk = (ABL && (a.dbg & 2048)) ? 0 : a.K_pad / BK;   // 2048: prologue + epilogue, no K-loop
 
   if (tid < BMP) {
     int m = pix0 + tid;
@@ -869,6 +870,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // MGD_DBG bits of the ablation build: 32 no epilogue, 64 no MFMA, 128 no pixel-fragment reads, 256 no weight-fragment
+  // loads, 512 no LDS-DMA; all constant false in the product build
+  const bool abl_e = ABL && (a.dbg & 32), abl_m = ABL && (a.dbg & 64), abl_x = ABL && (a.dbg & 128),
+             abl_a = ABL && (a.dbg & 256), abl_d = ABL && (a.dbg & 512);
 
   const int fr = lane & 15, fq = lane >> 4;
   int xro[NT];
@@ -877,7 +882,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   // weight fragments: block (tc, ks) = 1024 chunks of 16 B; this wave's eight start at wc*512.  NST register sets: the
   // set of step ks + NST - 1 is requested together with ring stage ks + NST - 1, so both operands have NST - 1 K-steps
   // to arrive (with a single step of distance the round trip of the weight loads sets the K-step, whatever the ring depth)
-  const uint4* wl = (const uint4*)a.wpk + ((size_t)tc * nk * 16 + (size_t)wc * 8) * 64 + lane;
+  const uint4* wl = (const uint4*)a.wpk + ((size_t)tc * nk * 16 + (size_t)wc * (MT * 2)) * 64 + lane;
   bf16x8 af[NST][MT][2];
   auto load_a = [&](bf16x8 (&f)[MT][2], int ks) {
     const uint4* w = wl + (size_t)ks * 1024;
@@ -888,7 +893,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   };
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) { issue(s); load_a(af[s], s); }
+    if (s < nk) { if (!abl_d) issue(s); load_a(af[s], s); }
 
   constexpr int GRP = XCH + 2 * MT;                    // vector-memory instructions per stage: 4 LDS-DMA + 8 fragment loads
   for (int ks0 = 0; ks0 < nk; ks0 += NST) {
@@ -902,29 +907,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       else wait_vmcnt_tracked<0>();
       unsigned char* sb = smem + j * STAGE;
       __builtin_amdgcn_s_barrier();
+      // the first half's pixel fragments are requested before the next stage goes out: their LDS round trip then runs
+      // under the issue of the LDS-DMA and weight loads (all eight at once would not fit the 168 registers of three
+      // waves per SIMD)
+      bf16x8 xf[NT];
+      if (!abl_x) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + xro[n]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       const int jn = (j + NST - 1) % NST;               // static after unrolling
       if (ks + NST - 1 < nk) {
-        issue(jn);
-        load_a(af[jn], ks + NST - 1);
+        if (!abl_d) issue(jn);
+        if (!abl_a) load_a(af[jn], ks + NST - 1);
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 xf[NT];
+        if (kk == 1 && !abl_x) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + (xro[n] ^ (kk << 6)));
+          for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + (xro[n] ^ 64));
+        }
+        if (!abl_m) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][m][kk], xf[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][m][kk], xf[n], acc[m][n], 0, 0, 0);
+        }
       }
     }
   }
   __syncthreads();
+  if (abl_e) return;
   epi.template run<false, true>(a, acc, smem, row_dst, co0, tid);
 }
 
-template <int NST, int WPE>
+template <int NST, int WPE, int WC = 2>
 int launch_gemm8(GemmArgs& a, hipStream_t st) {
   a.tilesC = a.Co_pad / 128;
   a.nblk = a.tilesC * cdiv(a.M, 128);
@@ -932,13 +951,15 @@ int launch_gemm8(GemmArgs& a, hipStream_t st) {
   size_t epi = a.dst_f32 ? (size_t)128 * (128 * 4 + 16) : (size_t)128 * (128 * 2 + 16) + 4 * 2 * 128 * 4;
   a.aux = (int)(ring > epi ? ring : epi);
   size_t lds = (size_t)a.aux + 128 * 8 + 64;
-  auto k = conv_gemm8_kernel<NST, WPE>;
+  auto k = conv_gemm8_kernel<NST, WPE, false, WC>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_gemm8_kernel<NST, WPE, true, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), lds, st, a);
+  if (a.dbg & 0xFE0) hipLaunchKernelGGL((conv_gemm8_kernel<NST, WPE, true, WC>), dim3(a.nblk), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), lds, st, a);
   return 0;
 }
 
@@ -2488,7 +2509,12 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
       MGD_CHECK_LAUNCH("conv_gather_gemm(producer/consumer)");
       return MGD_OK;
     }
-    launch_gemm8<2, 3>(a, st);
+    static int g8wc = -1;
+    // four waves along the channels (32 x 128 wave tiles): every weight fragment is loaded by exactly one wave - with 2 x 2
+    // waves of 64 x 64 the two waves of a channel row fetch the same fragments, 48 KB instead of 32 KB per K-step through the
+    // CU's vector-memory path (64 B/clk): forward convs 2.91 -> 2.78 ms
+    if (g8wc < 0) { const char* e = getenv("MGD_GEMM8_WC"); g8wc = e ? atoi(e) : 4; }
+    if (g8wc == 4) launch_gemm8<2, 3, 4>(a, st); else launch_gemm8<2, 3, 2>(a, st);
     MGD_CHECK_LAUNCH("conv_gather_gemm(global weight fragments)");
     return MGD_OK;
   }
