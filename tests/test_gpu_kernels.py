@@ -336,7 +336,8 @@ def test_pack_batch_matches_single_packs(dev):
     from multigriddet_amd import ops
     g = torch.Generator().manual_seed(2)
     pairs, singles = [], []
-    for co, ci, k, s_ in ((64, 32, 3, 2), (88, 704, 1, 1), (176, 64, 3, 1), (32, 27, 1, 1)):
+    for co, ci, k, s_ in ((64, 32, 3, 2), (88, 704, 1, 1), (176, 64, 3, 1), (32, 27, 1, 1),
+                          (256, 128, 3, 1), (128, 256, 1, 1), (255, 256, 1, 1), (128, 64, 3, 2)):   # 128-row images: fragment order
         if ci == 27:
             pk = ops.PackedConv(co, 32, 1, 1, dev, need_dgrad=False, ci_master=27)
             pk2 = ops.PackedConv(co, 32, 1, 1, dev, need_dgrad=False, ci_master=27)
@@ -352,6 +353,39 @@ def test_pack_batch_matches_single_packs(dev):
         assert torch.equal(pk.fwd.view(torch.int16), pk2.fwd.view(torch.int16))
         for a, b in zip(pk.dgrad, pk2.dgrad):
             assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16))
+
+
+def _unfragment(img, rows_pad, k_pad):
+    """Row-major view of a packed image in MFMA-fragment order (include/mgd_hip.h, mgd_pack_weights): block (cot, ks) of
+    1024 16-byte chunks, chunk ((g*2 + kk)*64 + lane) = row cot*128 + g*16 + (lane & 15), columns ks*64 + (kk*4 + (lane >> 4))*8."""
+    nk = k_pad // 64
+    a = img.reshape(rows_pad // 128, nk, 8, 2, 4, 16, 8)        # cot, ks, g, kk, fq, fr, elem
+    a = a.permute(0, 2, 5, 1, 3, 4, 6)                           # cot, g, fr, ks, kk, fq, elem
+    return a.reshape(rows_pad, k_pad)
+
+
+def test_packed_image_fragment_order_layout(dev):
+    """The layout promised in include/mgd_hip.h for 128-row packed images (forward, transposed / data-gradient, and the
+    element-wise path of the 255-channel heads), element for element against numpy; smaller images stay row-major."""
+    from multigriddet_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for co, ci, k in ((256, 128, 3), (128, 192, 1), (255, 256, 1), (64, 128, 3)):
+        pk = ops.PackedConv(co, ci, k, 1, dev)
+        w = torch.randn(co, k * k, ci, generator=g)
+        pk.refresh(w.to(dev))
+        torch.cuda.synchronize()
+        wb = w.to(torch.bfloat16).float()
+        ref = torch.zeros(pk.fwd_copad, pk.fwd_kpad)
+        ref[:co, :k * k * ci] = wb.reshape(co, k * k * ci)
+        got = pk.fwd.float().cpu()
+        got = _unfragment(got, pk.fwd_copad, pk.fwd_kpad) if pk.fwd_copad % 128 == 0 else got
+        assert torch.equal(got, ref), (co, ci, k, "fwd")
+        img, kp, cp, taps, _ = pk.dgrad[0]
+        refd = torch.zeros(cp, kp)
+        refd[:ci, :k * k * co] = wb[:, taps, :].permute(2, 1, 0).reshape(ci, k * k * co)
+        gotd = img.float().cpu()
+        gotd = _unfragment(gotd, cp, kp) if cp % 128 == 0 else gotd
+        assert torch.equal(gotd, refd), (co, ci, k, "dgrad")
 
 
 def test_upsample_concat(dev):
