@@ -237,7 +237,7 @@ def main():
                             "pixel tile through an LDS-DMA ring, three blocks per CU: 3x3/1x1 conv forward + data gradient)",
                  "gemm128pc": "conv_gemm6_kernel<2,2,4,4,4> (128x128-tile bf16 MFMA gather-GEMM, producer/consumer waves)",
                  "wgrad128": "conv_wgrad2_kernel<2,2,4,2> (128x64-tile bf16 MFMA weight gradient, per-tap blocks, split-K, three blocks per CU)"}
-        pmc_keys = {"gemm128": "conv_gemm8_kernel<2, 3>", "gemm128pc": "conv_gemm6_kernel<2, 2, 4, 4",
+        pmc_keys = {"gemm128": "conv_gemm8_kernel<2, 3,", "gemm128pc": "conv_gemm6_kernel<2, 2, 4, 4",
                     "wgrad128": "conv_wgrad2_kernel<2, 2, 4, 2>"}
         step_ms = dt * 1e3 / args.steps
 
