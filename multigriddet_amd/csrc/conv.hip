@@ -1328,43 +1328,56 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 
   // Address generation off the critical path.  K runs over PIXELS here, so the rows a lane stages change every K-step;
   // the first version re-derived (image, row, column) of every row from its flat pixel index per step - two divisions
-  // with correction loops per LDS-DMA instruction, 510 VALU + 395 SALU instructions per 32 MFMA (ISA count), the loop was
-  // bound by instruction issue, not by the matrix cores or the DMA.  A lane's rows advance by exactly 64 pixels per K-step,
-  // so (image, row, column) are carried and advanced with a compare-and-wrap; the row's channel chunk never changes.
+  // with correction loops per LDS-DMA instruction, 510 VALU + 395 SALU instructions per 32 MFMA (ISA count); carrying the
+  // coordinates left 173 + 83, and an ablation build still put HALF of the kernel's time into this skeleton (128->256 at
+  // 76x76: 53 of 106 us with MFMA, fragment reads and LDS-DMA all switched off) - with three waves per SIMD every VALU
+  // instruction costs 12 cycles of a SIMD's issue.  Now the source ADDRESS itself is carried (a lane's rows advance by
+  // exactly 64 pixels per K-step: one uniform 64-bit increment, plus a constant when the column / the row wraps), and
+  // (row, column) survive only for the validity test, done as two unsigned range compares against per-tap bounds.
   // Uniform values are pinned in SGPRs (a scalar re-load from the argument segment inside the loop drains lgkmcnt).
-  const int Wg = sgpr(a.Wg), Hg = sgpr(a.Hg), Hs = sgpr(a.Hs), Ws = sgpr(a.Ws), Ci = sgpr(a.Ci), Co = sgpr(a.Co);
-  const int sst = sgpr(a.in_stride), q64 = sgpr(64 / a.Wg), r64 = sgpr(64 % a.Wg);
+  const int Wg = sgpr(a.Wg), Hg = sgpr(a.Hg);
+  const int q64 = sgpr(64 / a.Wg), r64 = sgpr(64 % a.Wg);
   const int wraps = sgpr((64 / a.Wg + 1 + a.Hg - 1) / a.Hg);            // image wraps one 64-pixel advance can cross
-  const char* srcb = (const char*)a.src;
-  const char* dyb = (const char*)a.dy;
-  int o_cb[OCH];                 // byte offset of the lane's dy chunk inside a pixel row, or -1 (channel padding)
-  long long o_off[OCH];          // byte offset of the lane's dy chunk at the next K-step to issue
-  int o_p[OCH];
+  const int sst = a.in_stride;
+  // valid source rows / columns of this tap, as ranges of the OUTPUT coordinate: lo <= x <= lo + span
+  const int lo_i = __builtin_amdgcn_readfirstlane(dh < 0 ? (-dh + sst - 1) / sst : 0);
+  const int lo_j = __builtin_amdgcn_readfirstlane(dw < 0 ? (-dw + sst - 1) / sst : 0);
+  const int hi_i = min(a.Hg - 1, (a.Hs - 1 - dh) / sst), hi_j = min(a.Wg - 1, (a.Ws - 1 - dw) / sst);
+  const unsigned span_i = (unsigned)__builtin_amdgcn_readfirstlane(hi_i - lo_i);
+  const unsigned span_j = (unsigned)__builtin_amdgcn_readfirstlane(hi_j - lo_j);
+  const bool tap_ok = hi_i >= lo_i && hi_j >= lo_j;
+  long long dstep = (long long)a.Co * 128;                                                  // dy: 64 pixels further
+  long long xstep = ((long long)(64 / a.Wg) * sst * a.Ws + (long long)(64 % a.Wg) * sst) * a.Ci * 2;   // x: the same advance
+  long long xrow = ((long long)sst * a.Ws - (long long)a.Wg * sst) * a.Ci * 2;               // column wrapped: next output row
+  long long ximg = ((long long)a.Hs - (long long)a.Hg * sst) * a.Ws * a.Ci * 2;              // row wrapped: next image
+  asm volatile("" : "+s"(dstep), "+s"(xstep), "+s"(xrow), "+s"(ximg));
+  const char* o_ad[OCH];         // address of the lane's dy chunk at the next K-step to issue
+  int o_left[OCH];               // pixels left in the block's range from this row on (<= 0: past the end / channel padding)
 #pragma unroll
   for (int i = 0; i < OCH; ++i) {
     const int r = (i * 4 + wave) * ORPI + o_rl;
     const int ch = (((o_s >> 1) ^ tr_swz(r, RBO / 32)) << 1) | (o_s & 1);
     const int c = co0 + ch * 8;
-    o_cb[i] = c < Co ? c * 2 : -1;
-    o_p[i] = pbeg + r;
-    o_off[i] = (long long)o_p[i] * Co * 2 + c * 2;
+    o_left[i] = c < a.Co ? pend - (pbeg + r) : -(1 << 30);
+    o_ad[i] = (const char*)a.dy + ((long long)(pbeg + r) * a.Co + c) * 2;
   }
-  int x_cb[ICH], x_p[ICH], x_n[ICH], x_i[ICH], x_j[ICH];
+  const char* x_ad[ICH];
+  int x_left[ICH], x_i[ICH], x_j[ICH];
 #pragma unroll
   for (int i = 0; i < ICH; ++i) {
     const int r = (i * 4 + wave) * IRPI + i_rl;
     const int ch = (((i_s >> 1) ^ tr_swz(r, RBI / 32)) << 1) | (i_s & 1);
     const int c = ci0 + ch * 8;
-    x_cb[i] = c < Ci ? c * 2 : -1;
     const int pix = pbeg + r, hw = a.Hg * a.Wg;
-    x_p[i] = pix;
-    x_n[i] = pix / hw;
-    const int rem = pix - x_n[i] * hw;
+    const int n = pix / hw, rem = pix - n * hw;
+    x_left[i] = (c < a.Ci && tap_ok) ? pend - pix : -(1 << 30);
     x_i[i] = rem / a.Wg;
     x_j[i] = rem - x_i[i] * a.Wg;
+    // may point outside the tensor where the tap leaves the image: such rows are never fetched
+    x_ad[i] = (const char*)a.src + ((((long long)n * a.Hs + (x_i[i] * sst + dh)) * a.Ws + (x_j[i] * sst + dw)) * a.Ci + c) * 2;
   }
 
-  // Staging the NEXT K-step (steps go out in order, each exactly once) is split in two: prep() derives the eight source
+  // Staging the NEXT K-step (steps go out in order, each exactly once) is split in two: prep() picks the eight source
   // addresses and advances the carried state - plain VALU work, placed behind the first MFMAs of the PREVIOUS step, where
   // it runs in the shadow of the matrix pipe - and fire() is the eight LDS-DMA instructions alone, right after the barrier:
   // with a two-deep ring the DMA round trip is the step's critical path, and nothing may sit between barrier and issue.
@@ -1373,27 +1386,26 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
   auto prep = [&]() {
 #pragma unroll
     for (int i = 0; i < OCH; ++i) {
-      const bool v = o_p[i] < pend && o_cb[i] >= 0;
-      og[i] = v ? (const void*)(dyb + o_off[i]) : zero;
-      o_p[i] += 64;
-      o_off[i] += (long long)Co * 128;
+      og[i] = o_left[i] > 0 ? (const void*)o_ad[i] : zero;
+      o_left[i] -= 64;
+      o_ad[i] += dstep;
     }
 #pragma unroll
     for (int i = 0; i < ICH; ++i) {
-      const int hs = x_i[i] * sst + dh, ws = x_j[i] * sst + dw;
-      const bool v = x_p[i] < pend && x_cb[i] >= 0 && (unsigned)hs < (unsigned)Hs && (unsigned)ws < (unsigned)Ws;
-      const int lin = (x_n[i] * Hs + hs) * Ws + ws;
-      xg[i] = v ? (const void*)(srcb + (long long)lin * (Ci * 2) + x_cb[i]) : zero;
-      x_p[i] += 64;
+      const bool v = x_left[i] > 0 && (unsigned)(x_i[i] - lo_i) <= span_i && (unsigned)(x_j[i] - lo_j) <= span_j;
+      xg[i] = v ? (const void*)x_ad[i] : zero;
+      x_left[i] -= 64;
+      x_ad[i] += xstep;
       x_j[i] += r64;
       x_i[i] += q64;
-      const int cj = x_j[i] >= Wg ? 1 : 0;               // branch-free carries: exec-mask branches cost more than the selects
+      const bool cj = x_j[i] >= Wg;                      // branch-free carries: exec-mask branches cost more than the selects
       x_j[i] -= cj ? Wg : 0;
-      x_i[i] += cj;
+      x_i[i] += cj ? 1 : 0;
+      x_ad[i] += cj ? xrow : 0ll;
       for (int w = 0; w < wraps; ++w) {
-        const int cn = x_i[i] >= Hg ? 1 : 0;
+        const bool cn = x_i[i] >= Hg;
         x_i[i] -= cn ? Hg : 0;
-        x_n[i] += cn;
+        x_ad[i] += cn ? ximg : 0ll;
       }
     }
   };
