@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Timing of the per-tap weight-gradient kernel on one layer; MGD_DBG=16 swaps its fp32 atomics for plain stores, 32 drops
+the epilogue.  usage: [MGD_DBG=16|32] python tools/ablate_wgrad.py cin cout H [k]"""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multigriddet_amd import ops
 ci, co, h = (int(v) for v in sys.argv[1:4])
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 3
