@@ -208,9 +208,6 @@ int mgd_bias_grad(const void* dy_bf16, float* dbias, int64_t P, int C, void* str
 int mgd_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int mgd_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 
-/* diagnostic: phase-stamp sums of the stamped gather-GEMM build (MGD_DBG=2), cleared on read; out_host[8]. */
-int mgd_debug_read_stamps(unsigned long long* out_host);
-
 /* Adam with Keras semantics (config/model_builder.py:86-96): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
  * p -= lr_t*m/(sqrt(v)+eps).  grad_scale multiplies g first (1/world for DP averaging).
  * weight_decay > 0 gives AdamW (decoupled, Keras: p -= lr*wd*p). */

@@ -36,8 +36,7 @@ struct GemmArgs {
   int tilesC;   // Co_pad / BNC
   int nblk;
   int aux;      // conv_gemm8_kernel: byte offset of row_dst in LDS (behind the ring / the epilogue tile)
-  int dbg;      // diagnostic only (MGD_DBG): 1 = all LDS-DMA loads hit one cache line, 2 = phase stamps
-  unsigned long long* stamps;
+  int dbg;      // diagnostic only (MGD_DBG): 1 = all LDS-DMA loads hit one cache line; 32...2048: ablation build of conv_gemm8_kernel
   // fused BN-backward reduction of the CONSUMER layer over the tile just produced (dst = da of that layer)
   const bf16_t* bn_y;
   const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
@@ -88,7 +87,7 @@ __device__ __forceinline__ void wait_vmcnt_tracked() {
   __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
-template <int WC, int WP, int MT, int NT, int NST, bool STAMP = false>
+template <int WC, int WP, int MT, int NT, int NST>
 __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
   constexpr int BNC = WC * MT * 16;
   constexpr int BMP = WP * NT * 16;
@@ -246,27 +245,15 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
 #pragma unroll
   for (int n = 0; n < NT; ++n) xro[n] = BNC * ROWB + lds_off((wp * NT + n) * 16 + fr, fq);
 
-  // diagnostic build only (STAMP): cycles per phase of the K-loop, summed per wave, one atomic per wave at
-  // the end into a.stamps[0..4] = {wait vmcnt, zero-fix + barrier, LDS-DMA issue, fragment reads + MFMA, loops}
-  unsigned long long tw = 0, tb = 0, ti = 0, tcomp = 0, t0 = 0, t1 = 0;
-  auto stamp = [&]() -> unsigned long long {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-  };
   for (int ks = 0; ks < nk; ++ks) {
-    if (STAMP) { __builtin_amdgcn_sched_barrier(0); t0 = stamp(); __builtin_amdgcn_sched_barrier(0); }
     int pending = min(NST - 2, nk - 1 - ks);
     if (NST >= 4 && pending >= 2) wait_vmcnt<2 * LPS>();
     else if (NST >= 3 && pending == 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
-    if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp(); tw += t1 - t0; __builtin_amdgcn_sched_barrier(0); }
     const int cur = ks % NST;
     unsigned char* sb = smem + cur * STAGE;
     __builtin_amdgcn_s_barrier();
-    if (STAMP) { __builtin_amdgcn_sched_barrier(0); t0 = stamp(); tb += t0 - t1; __builtin_amdgcn_sched_barrier(0); }
     if (ks + NST - 1 < nk) issue(ks + NST - 1, (ks + NST - 1) % NST);
-    if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp(); ti += t1 - t0; __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 wf[MT], xf[NT];
@@ -280,16 +267,6 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
         for (int n = 0; n < NT; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
     }
-    if (STAMP) {
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-      t0 = stamp(); tcomp += t0 - t1;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  if (STAMP && a.stamps && lane == 0) {
-    atomicAdd(a.stamps + 0, tw); atomicAdd(a.stamps + 1, tb); atomicAdd(a.stamps + 2, ti); atomicAdd(a.stamps + 3, tcomp);
-    atomicAdd(a.stamps + 4, (unsigned long long)nk);
   }
   __syncthreads();
 
@@ -2306,7 +2283,6 @@ unsigned long long make_tapcode(int ntaps, const int32_t* dh, const int32_t* dw,
   return code;
 }
 
-__device__ unsigned long long g_stamps[8];
 
 template <int WC, int WP, int MT, int NT, int NST>
 int launch_gemm2(GemmArgs& a, hipStream_t st) {
@@ -2467,7 +2443,6 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("MGD_DBG"); dbg = e ? atoi(e) : 0; }
   a.dbg = dbg;
-  a.stamps = nullptr;
   a.bn_y = (const bf16_t*)d->bn_y; a.bn_scale = d->bn_scale; a.bn_shift = d->bn_shift; a.bn_mean = d->bn_mean;
   a.bn_invstd = d->bn_invstd; a.bn_sums = d->bn_sums; a.bn_slope = d->bn_slope;
   a.act_slope = d->act_slope;
@@ -2745,11 +2720,3 @@ extern "C" int mgd_pack_weights_batch(const mgd_pack_job* jobs_dev, int njobs, i
   return MGD_OK;
 }
 
-// diagnostic: read and clear the phase-stamp sums of the stamped gemm build (MGD_DBG=2)
-extern "C" int mgd_debug_read_stamps(unsigned long long* out_host) {
-  unsigned long long* dptr = nullptr;
-  if (hipGetSymbolAddress((void**)&dptr, HIP_SYMBOL(g_stamps)) != hipSuccess) return MGD_ELAUNCH;
-  if (hipMemcpy(out_host, dptr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return MGD_ELAUNCH;
-  (void)hipMemset(dptr, 0, 8 * sizeof(unsigned long long));
-  return MGD_OK;
-}
