@@ -1278,7 +1278,6 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
   constexpr int OCH = RBO / 64, ICH = RBI / 64;        // LDS-DMA instructions per wave per stage
   constexpr int ORPI = 1024 / RBO, IRPI = 1024 / RBI;  // rows per wave-instruction
   constexpr int STAGE = 64 * (RBO + RBI);
-  constexpr int EROW = (BCI + 4) * 4;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -1466,30 +1465,25 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
     wait_lgkm_dyn(0);
     mfma_half(1);
   }
-  __syncthreads();
-
+  // epilogue straight from the accumulators: a lane's (m, n, r) element belongs to channel row (wc*MT + m)*16 + fq*4 + r
+  // and column (wi*NT + n)*16 + fr, so the 16 lanes of equal fq add 64 contiguous bytes - one memory-side atomic request,
+  // the same as from an LDS-staged tile, without the LDS round trip and its two barriers
   const int fr = lane & 15, fq = lane >> 4;
+  if (a.dbg & 32) return;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + (wc * MT + m) * 16 + fq * 4 + r;
+      if (co >= a.Co) continue;
+      float* row = a.dw + ((long long)co * a.ntaps + tap) * a.Ci;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int col = (wc * MT + m) * 16 + fq * 4 + r;
-        int cil = (wi * NT + n) * 16 + fr;
-        *(float*)(smem + col * EROW + cil * 4) = acc[m][n][r];
+      for (int n = 0; n < NT; ++n) {
+        const int ci = ci0 + (wi * NT + n) * 16 + fr;
+        if (ci >= a.Ci) continue;
+        if (a.dbg & 16) row[ci] = acc[m][n][r]; else atomicAdd(row + ci, acc[m][n][r]);
       }
-  __syncthreads();
-  for (int q = tid; q < BCO * BCI; q += 256) {
-    int col = q / BCI, cil = q - col * BCI;
-    int co = co0 + col, ci = ci0 + cil;
-    if (co < a.Co && ci < a.Ci) {
-      float v = *(const float*)(smem + col * EROW + cil * 4);
-      float* dst = a.dw + ((long long)co * a.ntaps + tap) * a.Ci + ci;
-      if (a.dbg & 32) continue;
-      if (a.dbg & 16) *dst = v; else atomicAdd(dst, v);
     }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2353,9 +2347,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   constexpr int BCO = WC * MT * 16, BCI = WI * NT * 16;
   a.tilesCo = cdiv(a.Co, BCO);
   a.tilesCi = cdiv(a.Ci, BCI);
-  size_t stage = (size_t)64 * (BCO + BCI) * 2 * 2;
-  size_t epi = (size_t)BCO * (BCI + 4) * 4;
-  size_t lds = stage > epi ? stage : epi;
+  size_t lds = (size_t)64 * (BCO + BCI) * 2 * 2;       // the two-stage ring; the epilogue needs no LDS
   auto k = conv_wgrad2_kernel<WC, WI, MT, NT>;
   static bool attr = false;
   if (!attr) {
