@@ -2684,6 +2684,8 @@ extern "C" int mgd_pack_weights(const float* w, void* out, int Co, int T, int Ci
   }
   int rows = transpose ? Ci : Co, cin = transpose ? Co : Ci;
   MGD_REQUIRE(rows_pad >= rows && K_pad >= ntaps_out * cin, "pack: padded sizes too small");
+  // images of 128-row tiles are written in MFMA-fragment order (packed_elem): blocks of 128 rows x 64 K
+  MGD_REQUIRE((rows_pad & 127) || K_pad % 64 == 0, "pack: K_pad=%d must be a multiple of 64 for 128-row (fragment-order) images", K_pad);
   long long tot = (long long)rows_pad * K_pad;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)out,
                      Co, T, Ci, transpose, ntaps_out, code, rows_pad, K_pad);

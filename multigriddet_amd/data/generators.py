@@ -13,6 +13,11 @@
    input itself never changes size in the reference).  Mosaic / MixUp / GridMask and the target encoding run on the
    device.  `native_multiscale=True` is an extension: the sampled shape becomes the batch's resolution (the engine keeps
    one arena per resolution, BASELINE config 3).
+   Iterating the generator PREFETCHES (reference :2068-2131 `dataset.prefetch`, trainer.py:215-221): a background thread
+   fills a queue of `prefetch_factor` pinned host batches while the GPU trains, and the host-to-device copy of batch
+   i+1 runs on a copy stream under step i; `prefetch_factor=0` (and `gen[i]`) is the synchronous path.  Both paths draw
+   from the same per-purpose random streams (shuffle / shape / per-image seeds / device augmentation), so a fixed seed
+   gives identical batches either way.
 """
 import os
 from typing import List, Optional, Sequence, Tuple
@@ -67,7 +72,32 @@ def parse_annotation_line(line):
     return parts[0], boxes
 
 
-def letterbox(image, boxes, target_hw, fill=0):
+_ALLOC_TUNED = False
+
+
+def _tune_host_allocators():
+    """The loader threads allocate and free megabyte-sized image buffers at a high rate.  glibc serves those with
+    mmap/munmap (every buffer page-faults in again, and the threads serialise on the process's address-space lock) and
+    Pillow frees its image arenas at once: sixteen 608x608 PNGs took 78 ms on 8 threads, 28 ms with both caches on."""
+    global _ALLOC_TUNED
+    if _ALLOC_TUNED:
+        return
+    _ALLOC_TUNED = True
+    try:
+        from PIL import Image
+        Image.core.set_blocks_max(256)                 # keep freed 16-MiB image blocks for reuse
+    except Exception:
+        pass
+    try:
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 1 << 30)                      # M_MMAP_THRESHOLD: image-sized buffers from the heap
+        libc.mallopt(-1, 1 << 30)                      # M_TRIM_THRESHOLD: and the heap keeps them
+    except Exception:
+        pass
+
+
+def letterbox(image, boxes, target_hw, fill=0, dtype=np.float32):
     """Aspect-preserving resize (bicubic) + centred pad; boxes mapped along.  Training pads with zeros
     (tf.image.pad_to_bounding_box, reference generators.py:167-209); inference pads with 128
     (utils/preprocessing.py:46) - pass fill accordingly."""
@@ -77,13 +107,16 @@ def letterbox(image, boxes, target_hw, fill=0):
     r = min(tw / w, th / h)
     nw, nh = max(1, int(round(w * r))), max(1, int(round(h * r)))
     ox, oy = (tw - nw) // 2, (th - nh) // 2
-    canvas = Image.new("RGB", (tw, th), (fill, fill, fill))
-    canvas.paste(image.resize((nw, nh), Image.BICUBIC), (ox, oy))
+    if (nw, nh) == (tw, th):
+        canvas = image.resize((nw, nh), Image.BICUBIC)          # fills the frame: no pad to paste into
+    else:
+        canvas = Image.new("RGB", (tw, th), (fill, fill, fill))
+        canvas.paste(image.resize((nw, nh), Image.BICUBIC), (ox, oy))
     out = boxes.copy()
     if len(out):
         out[:, [0, 2]] = out[:, [0, 2]] * r + ox
         out[:, [1, 3]] = out[:, [1, 3]] * r + oy
-    return np.asarray(canvas, np.float32), out
+    return np.asarray(canvas, dtype), out
 
 
 class MultiGridDataGenerator:
@@ -93,7 +126,8 @@ class MultiGridDataGenerator:
                  multi_anchor_assign: bool = False, shuffle: bool = True, prefetch_factor: int = 2,
                  num_workers: int = 8, mosaic_prob: float = 0.3, mixup_prob: float = 0.1,
                  max_boxes_per_image: int = 100, seed: int = 0, gridmask_prob: float = 0.1,
-                 host_augment: Optional[bool] = None, native_multiscale: bool = False, **kwargs):
+                 host_augment: Optional[bool] = None, native_multiscale: bool = False,
+                 shape_seed: Optional[int] = None, **kwargs):
         if enhance_augment not in (None, "mosaic"):
             raise ValueError(f"enhance_augment={enhance_augment!r}: only None or 'mosaic' exist (reference generators.py:1505)")
         self.annotation_lines = list(annotation_lines)
@@ -108,7 +142,14 @@ class MultiGridDataGenerator:
         self.indexes = np.arange(len(self.annotation_lines))
         self.num_layers = len(anchors)
         self.grid_shapes = [(self.input_shape[0] // s, self.input_shape[1] // s) for s in (32, 16, 8, 4, 2)][:self.num_layers]
-        self.rng = np.random.default_rng(seed)
+        # one random stream per purpose, so that the order in which host loading (which runs ahead when prefetching) and
+        # device augmentation consume numbers cannot change the batches.  `shape_seed` seeds the multi-scale draw alone:
+        # data-parallel ranks pass their own `seed` (different permutations / augmentation draws per rank) but a COMMON
+        # shape_seed - every rank must train the same resolution in the same step.
+        ss = np.random.SeedSequence(int(seed)).spawn(3)
+        self.rng_shuffle, self.rng_host, self.rng = (np.random.default_rng(c) for c in ss)
+        self.rng_shape = np.random.default_rng(np.random.SeedSequence([int(seed if shape_seed is None else shape_seed), 7]))
+        self.prefetch_factor = max(0, int(prefetch_factor))
         self.host_augment = augment if host_augment is None else bool(host_augment)
         self.native_multiscale = bool(native_multiscale)
         self.num_workers = max(1, int(num_workers))
@@ -116,11 +157,12 @@ class MultiGridDataGenerator:
         self.input_shape_list = get_multiscale_list()
         self._executor = None
         if shuffle:
-            self.rng.shuffle(self.indexes)
+            self.rng_shuffle.shuffle(self.indexes)
 
     def _pool(self):
         if self._executor is None and self.num_workers > 1:
             from concurrent.futures import ThreadPoolExecutor
+            _tune_host_allocators()
             self._executor = ThreadPoolExecutor(max_workers=self.num_workers)
         return self._executor
 
@@ -135,7 +177,7 @@ class MultiGridDataGenerator:
 
     def on_epoch_end(self):
         if self.shuffle:
-            self.rng.shuffle(self.indexes)
+            self.rng_shuffle.shuffle(self.indexes)
 
     def _load(self, line, target_shape=None, out_shape=None, seed=None):
         """One image: decode -> letterbox to target_shape (-> bilinear resize to out_shape when they differ, the
@@ -145,16 +187,18 @@ class MultiGridDataGenerator:
         out_shape = tuple(out_shape or target_shape)
         path, boxes = parse_annotation_line(line)
         img = Image.open(path).convert("RGB")
-        im, bx = letterbox(img, boxes, target_shape, fill=0)
+        # 8-bit until something needs fractions: without host augmentation the batch crosses PCIe as uint8 (a quarter of
+        # the bytes) and is widened on the device
+        im, bx = letterbox(img, boxes, target_shape, fill=0, dtype=np.uint8)
         if out_shape != target_shape:
             oh, ow = out_shape
-            im = np.asarray(Image.fromarray(im.astype(np.uint8)).resize((ow, oh), Image.BILINEAR), np.float32)
+            im = np.asarray(Image.fromarray(im).resize((ow, oh), Image.BILINEAR))
             if len(bx):
                 bx[:, [0, 2]] *= ow / target_shape[1]
                 bx[:, [1, 3]] *= oh / target_shape[0]
         if self.host_augment:
             from . import host_aug
-            im, bx = host_aug.augment_image(np.random.default_rng(seed), im, bx, out_shape)
+            im, bx = host_aug.augment_image(np.random.default_rng(seed), im.astype(np.float32), bx, out_shape)
         return im, bx
 
     def next_shape(self):
@@ -162,12 +206,20 @@ class MultiGridDataGenerator:
         if self.rescale_interval > 0:
             self.rescale_step = (self.rescale_step + 1) % self.rescale_interval
             if self.rescale_step == 0:
-                return self.input_shape_list[int(self.rng.integers(0, len(self.input_shape_list)))]
+                return self.input_shape_list[int(self.rng_shape.integers(0, len(self.input_shape_list)))]
         return self.input_shape
 
-    def load_batch(self, i):
-        """Host part: returns (images uint8-range fp32 [B,H,W,3], boxes [B, capacity, 5]).  The last batch of an epoch is
-        filled up from the start of the (shuffled) index list, so every batch has batch_size images."""
+    @staticmethod
+    def _host_buffer(shape, dtype, pinned):
+        if pinned and torch.cuda.is_available():
+            t = torch.empty(shape, dtype=torch.float32 if dtype == np.float32 else torch.uint8, pin_memory=True)
+            return t.numpy()                           # the array keeps the pinned tensor alive (its .base)
+        return np.zeros(shape, dtype)
+
+    def load_batch(self, i, pinned=False):
+        """Host part: returns (images in the uint8 range [B,H,W,3] - uint8, or fp32 after host augmentation -, boxes
+        [B, capacity, 5]).  The last batch of an epoch is filled up from the start of the (shuffled) index list, so
+        every batch has batch_size images.  pinned: page-locked image buffer (asynchronous host-to-device copy)."""
         idx = self.indexes[i * self.batch_size:(i + 1) * self.batch_size]
         if len(idx) < self.batch_size:
             idx = np.concatenate([idx, np.resize(self.indexes, self.batch_size - len(idx))])
@@ -175,9 +227,9 @@ class MultiGridDataGenerator:
         target = tuple(self.next_shape())
         out = target if self.native_multiscale else self.input_shape
         H, W = out
-        images = np.zeros((self.batch_size, H, W, 3), np.float32)
+        images = self._host_buffer((self.batch_size, H, W, 3), np.float32 if self.host_augment else np.uint8, pinned)
         boxes = np.zeros((self.batch_size, cap, 5), np.float32)
-        seeds = self.rng.integers(0, 2 ** 31 - 1, size=len(idx))
+        seeds = self.rng_host.integers(0, 2 ** 31 - 1, size=len(idx))
         jobs = [(self.annotation_lines[k], target, out, int(sd)) for k, sd in zip(idx, seeds)]
         pool = self._pool()
         results = list(pool.map(lambda a: self._load(*a), jobs)) if pool else [self._load(*a) for a in jobs]
@@ -192,6 +244,9 @@ class MultiGridDataGenerator:
         """Device part: batch augmentation (uint8-range) -> /255 -> targets.  images/boxes numpy or CUDA."""
         img = torch.as_tensor(images).cuda().float().contiguous()
         bx = torch.as_tensor(boxes).cuda().float().contiguous()
+        return self._device_part(img, bx)
+
+    def _device_part(self, img, bx):
         B, S = img.shape[0], img.shape[1]
         if self.augment and img.shape[1] == img.shape[2]:
             if self.enhance_augment == "mosaic" and B >= 4 and self.rng.uniform() < self.mosaic_prob:
@@ -219,5 +274,73 @@ class MultiGridDataGenerator:
         return self
 
     def __iter__(self):
-        for i in range(len(self)):
-            yield self[i]
+        if self.prefetch_factor <= 0 or not torch.cuda.is_available():
+            for i in range(len(self)):
+                yield self[i]
+            return
+        yield from self._iter_prefetch()
+
+    def _iter_prefetch(self):
+        """One epoch with the host path running ahead: a producer thread calls load_batch(i) in order (fanning the images
+        of a batch out to the worker pool) into a queue of `prefetch_factor` pinned batches; the consumer uploads batch
+        i+1 on a copy stream before it hands out batch i, so decode, letterbox, host augmentation and the PCIe copy all
+        run under the GPU's step.  Random draws: see __init__ (identical to the synchronous path)."""
+        import queue
+        import threading
+        n = len(self)
+        q = queue.Queue(maxsize=self.prefetch_factor)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for i in range(n):
+                    if stop.is_set():
+                        return
+                    item = self.load_batch(i, pinned=True)
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+            except BaseException as e:                 # surfaces in the consumer, not in a dead thread
+                q.put(e)
+
+        th = threading.Thread(target=produce, name="mgd-prefetch", daemon=True)
+        th.start()
+        if not hasattr(self, "_copy_stream"):
+            self._copy_stream = torch.cuda.Stream()
+        cs = self._copy_stream
+
+        def upload():
+            item = q.get()
+            if isinstance(item, BaseException):
+                raise item
+            images, boxes = item
+            with torch.cuda.stream(cs):
+                img = torch.from_numpy(images).cuda(non_blocking=True)
+                bx = torch.from_numpy(boxes).cuda(non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(cs)
+            return img, bx, ev, images               # `images` keeps the pinned source alive until the copy is waited for
+
+        try:
+            staged = upload() if n > 0 else None
+            for i in range(n):
+                img, bx, ev, _keep = staged
+                staged = upload() if i + 1 < n else None      # batch i+1 crosses PCIe while batch i trains
+                ev.synchronize()          # the copy was enqueued a whole step ago; behind it the pinned source may go
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev)
+                img.record_stream(cur)
+                bx.record_stream(cur)
+                dimg, _, y = self._device_part(img.float().contiguous(), bx.float().contiguous())
+                yield (dimg, *y), torch.zeros(self.batch_size, device=dimg.device)
+        finally:
+            stop.set()
+            try:
+                while True:
+                    q.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(timeout=5.0)

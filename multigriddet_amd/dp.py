@@ -18,6 +18,9 @@ def init_distributed(share_gpu=None):
     WORLD_SIZE <= 1.  share_gpu (default: MGD_BENCH_SHARE_GPU=1): rehearsal on a one-GPU box - every rank on cuda:0,
     gloo for the exchange (RCCL refuses two ranks on one device)."""
     import os
+    # read by the HSA runtime when it initialises (the first torch.cuda call of the process): set it before that, or the
+    # launcher has to export it (the host driver only supports dmabuf IPC)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -29,7 +32,6 @@ def init_distributed(share_gpu=None):
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu or not torch.cuda.is_available():
             dist.init_process_group(backend="gloo")
@@ -57,6 +59,24 @@ def broadcast_flag(flag, world, src=0):
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
     dist.broadcast(t, src=src)
     return bool(t.item())
+
+
+def broadcast_tensors(tensors, world, src=0):
+    """Rank `src`'s contents of every tensor for everyone, in place (initial weights, BatchNorm moving statistics,
+    optimiser state).  RCCL moves device tensors directly; under gloo (CPU tests, the shared-GPU rehearsal) CUDA tensors
+    are staged through the host."""
+    if world <= 1 or not dist.is_initialized():
+        return
+    direct = dist.get_backend() == "nccl"
+    for t in tensors:
+        if t is None or t.numel() == 0:
+            continue
+        if direct or not t.is_cuda:
+            dist.broadcast(t, src=src)
+        else:
+            h = t.detach().cpu()
+            dist.broadcast(h, src=src)
+            t.copy_(h)
 
 
 def shard_lines(lines, rank, world):

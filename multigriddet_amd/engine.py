@@ -484,8 +484,6 @@ class Network:
             dy1 = self._bwd_bn(A, c1, d_a1)
             xin = A["cat"][sc - 1] if sc > 0 else acts[BACKBONE_CONVS - 1]
             self._wgrad(xin, dy1, Lr[c1].dw, 1, 1)
-            if on_layer_done:
-                on_layer_done(c1)
             if sc > 0:
                 d_cat = self.O.conv_dgrad(dy1, Lr[c1].pk, hw[c1], out=self._scratch(A, "dcat", xin.shape))
                 lat = Lr[head0 + (sc - 1) * 6 + 5]
@@ -499,6 +497,10 @@ class Network:
             elif not train_head_only:
                 g_f1 = self.O.conv_dgrad(dy1, Lr[c1].pk, hw[c1], out=self._scratch(A, "g5", acts[BACKBONE_CONVS - 1].shape),
                                       bnred=self._bnred(A, BACKBONE_CONVS - 1))
+            # the hook comes AFTER the last reader of c1's packed weights (its data gradient above): with the per-bucket
+            # optimiser it re-packs Lr[c1].pk on the communication stream, which only waits for work enqueued before it
+            if on_layer_done:
+                on_layer_done(c1)
         if pred_only or train_head_only:
             self._join_wgrad()
             if on_layer_done:

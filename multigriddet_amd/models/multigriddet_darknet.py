@@ -245,6 +245,19 @@ class MultiGridDetTrainModel:
         self.ts = TrainStep(self.base.net, self.anchors, self.num_classes, self.input_shape, 0, loss_kwargs=lk,
                             lr=float(self.optimizer.learning_rate), optimizer=self.optimizer.kind,
                             opt_kwargs=self.optimizer.kwargs, world_size=self.world_size, class_weights=cw)
+        self.sync_replicas()
+
+    def sync_replicas(self):
+        """Data-parallel replicas start from rank 0's state: master weights, BatchNorm moving statistics and the
+        optimiser moments are broadcast and the packed bf16 images rebuilt from them (no-op for one process).  Without
+        it the ranks would only agree while every process happens to draw the same initial weights."""
+        if self.world_size <= 1:
+            return
+        from ..dp import broadcast_tensors
+        net = self.base.net
+        broadcast_tensors([net.params, net.moving, self.ts.m, self.ts.v], self.world_size)
+        if not net.fp32:
+            net.refresh_packed(0)
 
     def count_params(self):
         return self.base.count_params()
@@ -269,6 +282,7 @@ class MultiGridDetTrainModel:
             if self.ts.v is not None and "optimizer/v" in z:
                 self.ts.v.copy_(torch.from_numpy(z["optimizer/v"]))
             self.ts.step_count = int(z["optimizer/step"])
+        self.sync_replicas()
         return z
 
     def train_on_batch(self, inputs):

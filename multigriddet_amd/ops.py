@@ -123,6 +123,10 @@ class PackBatch:
                 j.w, j.out = w.data_ptr(), img.data_ptr()
                 j.Co, j.T, j.Ci, j.transpose, j.ntaps_out = pk.co, pk.T, pk.ci_master, tr, nt
                 j.rows_pad, j.K_pad = rows_pad, kpad
+                if rows_pad % 128 == 0 and kpad % 64:
+                    # the job table lives in device memory, so mgd_pack_weights_batch cannot check it: 128-row images are
+                    # written in fragment order (blocks of 128 rows x 64 K), as mgd_pack_weights enforces
+                    raise ValueError(f"PackBatch: K_pad={kpad} must be a multiple of 64 for a {rows_pad}-row image")
                 code = 0
                 for t, sidx in enumerate(st):
                     code |= int(sidx) << (4 * t)

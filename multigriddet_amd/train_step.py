@@ -149,7 +149,8 @@ class TrainStep:
             rng_ = net.trainable_range()
             lo = rng_[0] if rng_ else 0
             self.dp.reset(lo=lo)
-            per_bucket = self.bucket_optimizer and rng_ is not None
+            # fp32 (strict-parity) networks keep no packed bf16 images: their optimiser runs on the tail (apply_optimizer)
+            per_bucket = self.bucket_optimizer and rng_ is not None and not net.fp32
             self.dp.after_bucket = (lambda k, b, e: self._bucket_update(k, b, e, dev_hyper)) if per_bucket else None
             net.backward(douts, on_layer_done=self.dp.on_layer_done)
             self.dp.finish()      # makes the compute stream wait for the collectives (and the per-bucket updates)

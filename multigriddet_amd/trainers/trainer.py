@@ -108,9 +108,15 @@ class MultiGridTrainer:
             train_lines = shard_lines(box[0], self.rank, self.world)
         self.input_shape = tuple(preset["input_shape"][:2])
         ac = tc.get("augmentation", {})
+        dl = self.config.get("data_loader", {})
+        pb = dl.get("prefetch_buffer", "auto")        # batches; 'auto' / None = 6 (reference trainer.py:215-221)
+        prefetch = int(pb) if isinstance(pb, (int, float)) and not isinstance(pb, bool) else 6
+        base_seed = int(tc.get("seed", 0))
+        # every rank draws its own permutation and augmentation (seed + rank) but the SAME multi-scale shapes (shape_seed)
         common = dict(batch_size=tc["batch_size"], input_shape=self.input_shape, anchors=self.anchors,
                       num_classes=self.num_classes, multi_anchor_assign=tc.get("multi_anchor_assign", False),
-                      num_workers=self.config.get("data_loader", {}).get("num_workers", 8))
+                      num_workers=dl.get("num_workers", 8), prefetch_factor=prefetch,
+                      seed=base_seed + self.rank, shape_seed=base_seed)
         self.train_generator = MultiGridDataGenerator(
             annotation_lines=train_lines, augment=ac.get("enabled", True), enhance_augment=ac.get("enhance_type"),
             rescale_interval=ac.get("rescale_interval", -1), shuffle=True, mosaic_prob=ac.get("mosaic_prob", 0.3),

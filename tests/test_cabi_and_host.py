@@ -117,6 +117,18 @@ def test_argument_validation_returns_einval_with_message():
     assert lib.mgd_comm_destroy(None) == 0          # destroying nothing is not an error
 
 
+def test_pack_weights_rejects_unaligned_k_for_fragment_order_images():
+    """Images of 128-row tiles are written in MFMA-fragment order (blocks of 128 rows x 64 K): a K_pad that is not a
+    multiple of 64 would write past the image, so the C-ABI refuses it on the host."""
+    import ctypes as C
+    _lib = _build_if_needed()
+    lib = _lib.load()
+    taps = (C.c_int32 * 9)(*range(9))
+    fake = C.c_void_p(0x10000)                       # never dereferenced: validation fails first
+    rc = lib.mgd_pack_weights(fake, fake, 128, 9, 8, 0, 9, taps, 128, 72, None)
+    assert rc == -1 and b"multiple of 64" in lib.mgd_last_error(), lib.mgd_last_error()
+
+
 def test_conv_rejects_tensors_beyond_32bit_offsets():
     """The gather-GEMM kernels address the source tensor with 32-bit byte offsets from a scalar base: a source of 4 GiB
     or more must be refused on the host (MGD_EINVAL), not silently wrapped (include/mgd_hip.h, mgd_conv_desc limits)."""

