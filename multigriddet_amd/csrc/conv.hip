@@ -14,6 +14,7 @@
 // and leave as whole 16-byte/256-byte NHWC rows.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -43,6 +44,7 @@ struct GemmArgs {
   float* bn_sums;
   float bn_slope;
   float act_slope;   // != 0: LeakyReLU on (acc + bias) before the addend (BatchNorm-folded inference)
+  unsigned rowmask, colmask;   // conv_gemm9_kernel: 3 x 9 bits, the taps with dh + 1 == j / dw + 1 == j (bits 9j .. 9j+8)
 };
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * ROWB + ((kc ^ (row & 7)) << 4); }
@@ -947,6 +949,264 @@ int launch_gemm8(GemmArgs& a, hipStream_t st) {
 __device__ __forceinline__ int sgpr(int v) {
   asm volatile("" : "+s"(v));
   return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gather-GEMM with a hand-counted memory pipeline (round 3).  conv_gemm8_kernel keeps one stage in flight and drains
+// vmcnt(0) every K-step: hipcc cannot count LDS-DMA and register loads on one queue (it waits vmcnt(0) at the first use
+// of a loaded register), so a deeper ring never reached the hardware, and a K-step of a wave lasts one full load round
+// trip (~2600 cycles against 512 cycles of MFMA; three blocks per CU hide about half).  Here every vector-memory
+// instruction of the K-loop is issued from inline asm - the weight fragments as global_load_dwordx4 (SGPR base + lane
+// offset + immediate), the gathered pixel rows as buffer_load_dwordx4 ... lds - so the compiler sees no memory traffic in
+// the loop, and the waits are mine: s_waitcnt vmcnt((NST - 2) * GRP) leaves NST - 2 whole stages in flight across the
+// barrier.  The pixel source is a raw buffer descriptor over the activation tensor: a lane whose tap leaves the image (or
+// whose K index is padding) presents an out-of-range offset and the hardware writes zeros - no zero page, no 64-bit
+// select.  Tap and channel of a K-step are wave-uniform (requires ntaps == 1 or Ci % 64 == 0): one scalar byte offset per
+// K-step, per DMA a mask test, a select and an add.
+// Tile 128 channels x 16*NT pixels (NT = 8, 6, 4: the host picks the pixel tile that fills the 512 block slots best),
+// 4 waves of 32 channels x 16*NT pixels, NST-deep ring of pixel stages, NST register sets of weight fragments, 2 blocks
+// per CU (<= 256 registers).  Persistent: the grid is min(tiles, 512) and a block walks tiles blockIdx.x + i * gridDim.x.
+template <int XCH>
+__device__ __forceinline__ void dma_rows_asm(const unsigned (&voff)[XCH], i32x4 srd, unsigned lds_dst) {
+  unsigned keep;
+  if constexpr (XCH == 4) {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %6, 0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %6, 0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, 0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(lds_dst), "s"(srd) : "memory", "scc");
+  } else if constexpr (XCH == 3) {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, 0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(lds_dst), "s"(srd) : "memory", "scc");
+  } else {
+    static_assert(XCH == 2, "pixel pieces per wave and stage");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, 0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "s"(lds_dst), "s"(srd) : "memory", "scc");
+  }
+}
+
+// the four weight fragments of a K-step (2 channel groups x 2 k-halves), 1 KiB apart in the fragment-ordered image
+__device__ __forceinline__ void load_a4_asm(bf16x8 (&f)[2][2], unsigned lane16, const void* sbase) {
+  asm volatile("global_load_dwordx4 %0, %4, %5 offset:0\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+               "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"
+               : "=&v"(f[0][0]), "=&v"(f[0][1]), "=&v"(f[1][0]), "=&v"(f[1][1]) : "v"(lane16), "s"(sbase) : "memory");
+}
+
+// counted wait that also pins the register set it releases: nothing may read f before this statement
+template <int N>
+__device__ __forceinline__ void wait_a4(bf16x8 (&f)[2][2]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]) : "n"(N) : "memory");
+}
+
+template <int NT, int NST, int WPE, int WCNT = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void conv_gemm9_kernel(GemmArgs a) {
+  constexpr int WC = 4, WP = 1, MT = 2, BNC = 128, BMP = 16 * NT, NTHR = 256;
+  constexpr int RPR = NTHR / 8, XCH = BMP / RPR;           // 32 rows per DMA round; 4 / 3 / 2 pixel pieces per wave and stage
+  constexpr int STAGE = BMP * ROWB;
+  constexpr int GRP = 4 + XCH;                              // vector-memory instructions per stage and wave
+  static_assert(NST >= 2 && NST <= 4, "ring depth");
+  using Epi = GemmEpilogue<WC, WP, MT, NT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  long long* row_dst = (long long*)(smem + a.aux);
+  uint2* row_src = (uint2*)(smem + a.aux + BMP * 8);        // per pixel row: byte offset of its centre pixel, tap-validity mask
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = a.K_pad / BK;
+  const int Kreal = a.ntaps * a.Ci;
+  const unsigned lds0 = lds_addr(smem) + wave * 1024;
+
+  i32x4 srd;
+  {
+    const unsigned long long p = (unsigned long long)a.src;
+    srd[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+    srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    srd[2] = __builtin_amdgcn_readfirstlane((unsigned)((long long)a.N * a.Hs * a.Ws * a.Ci * 2));
+    srd[3] = 0x00020000;
+  }
+  const unsigned OOB = 0xFFFFFFF0u;                         // beyond any tensor the host admits (< 4 GiB): reads as zeros
+
+  const int rlo = tid >> 3;
+  const int kc = (tid & 7) ^ (rlo & 7);
+  const int fr = lane & 15, fq = lane >> 4;
+  int xro[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) xro[n] = lds_off(n * 16 + fr, fq);
+  const unsigned lane16 = lane * 16;
+
+  for (int t = blockIdx.x; t < a.nblk; t += gridDim.x) {
+    Epi epi;                                                   // per tile: none of its registers lives across the K-loop
+    const int L = xcd_remap(t, a.nblk);
+    const int tc = L % a.tilesC, tp = L / a.tilesC;
+    const int co0 = tc * BNC, pix0 = tp * BMP;
+    lds_barrier();                                             // the previous tile's epilogue has left the ring and the row tables
+    // row tables, one pixel per thread: destination element offset, source byte offset, and which taps stay inside the
+    // image - the set of taps with a valid row AND a valid column (a.rowmask / a.colmask: taps by dh + 1 / dw + 1, 9 bits each)
+    if (tid < BMP) {
+      int m = pix0 + tid;
+      long long off = -1;
+      unsigned xo = 0, vm = 0;
+      if (m < a.M) {
+        int hw = a.Hg * a.Wg;
+        int n = m / hw, rem = m - n * hw;
+        int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+        int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
+        off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
+        int hs = ig * a.in_stride, ws = jg * a.in_stride;
+        xo = (unsigned)(((((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci) * 2);
+        unsigned rsel = 0, csel = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if ((unsigned)(hs + j - 1) < (unsigned)a.Hs) rsel |= (a.rowmask >> (9 * j)) & 0x1FFu;
+          if ((unsigned)(ws + j - 1) < (unsigned)a.Ws) csel |= (a.colmask >> (9 * j)) & 0x1FFu;
+        }
+        vm = rsel & csel;
+      }
+      row_dst[tid] = off;                                      // read by the epilogue, many barriers from here
+      row_src[tid] = make_uint2(xo, vm);
+    }
+    lds_barrier();
+    unsigned xoff[XCH], vmask[XCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const uint2 rs = row_src[rlo + RPR * i];
+      xoff[i] = rs.x + kc * 16;
+      vmask[i] = rs.y;
+    }
+    // wave-uniform K-step state: tap bit, first channel, byte offset of (tap, channel) relative to the centre pixel
+    int s_tap = 0, s_c0 = 0, s_k0 = 0;
+    auto tap_off = [&](int tp_) {
+      const int dh = (int)((a.tapcode >> (4 * tp_)) & 3) - 1;
+      const int dw = (int)((a.tapcode >> (4 * tp_ + 2)) & 3) - 1;
+      return (dh * a.Ws + dw) * a.Ci * 2;
+    };
+    int s_toff = tap_off(0);
+    // weight fragments of (tile tc, K-step ks): 16 KiB, this wave's four fragments start at wave * 4 KiB
+    const char* abase = (const char*)a.wpk + ((size_t)tc * nk * 16 + (size_t)wave * 4) * 1024;
+    int s_issued = 0;
+    // Issues the next stage.  Past the last K-step it issues a DUMMY stage instead - every pixel lane out of range (no memory
+    // traffic, zeros into a ring slot nobody reads again), the weight fragments of the last step once more - so that every
+    // K-step of the loop below is the same straight code with the same wait count: no branch between a load and its wait.
+    auto issue = [&](int buf, bf16x8 (&f)[2][2]) {
+      const bool real = s_issued < nk;
+      const unsigned bit = 1u << s_tap;
+      const bool kin = real && (s_k0 + kc * 8 < Kreal);       // K padding of the last step reads as zeros
+      unsigned vo[XCH];
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) vo[i] = ((vmask[i] & bit) && kin) ? xoff[i] + (unsigned)s_toff : OOB;
+      dma_rows_asm<XCH>(vo, srd, lds0 + buf * STAGE);
+      load_a4_asm(f, lane16, abase + (size_t)min(s_issued, nk - 1) * 16384);
+      ++s_issued;
+      if (real) {
+        s_k0 += BK;
+        s_c0 += BK;
+        s_toff += BK * 2;
+        if (s_c0 >= a.Ci) { s_c0 -= a.Ci; ++s_tap; s_toff = tap_off(s_tap) + s_c0 * 2; }
+      }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 af[NST][2][2];
+    // One K-step on register set / ring stage J: wait until all but WS vector-memory operations of this wave have completed,
+    // meet the block, read the pixel fragments, issue stage J + NST - 1, multiply (MUL: the padded steps of the last group
+    // only keep the pipeline's count).  J is compile-time and the body has no branch between a load and its wait: a register
+    // set that is still in flight must never pass through a compiler-made copy (a v_mov of a pending load destination reads
+    // garbage) - 'if' ladders around the waits and a 'break' inside the unrolled body both made hipcc merge differently
+    // allocated copies of the sets in front of the wait.
+    // LDS-DMA and register loads are not known to return in order with respect to each other: a count proves "the oldest
+    // stage has landed" only when the survivors of EITHER kind must belong to younger stages, i.e. min(DMA, register loads)
+    // per stage in flight (WCNT = 1, MGD_GEMM9_CNT=1: the full group count, for the A/B measurement)
+    constexpr int SAFE = WCNT ? GRP : (XCH < 4 ? XCH : 4);
+    constexpr int WS = (NST - 2) * SAFE;
+    auto step = [&](auto jc, bool mul) {
+      constexpr int J = decltype(jc)::value;
+      constexpr int JN = (J + NST - 1) % NST;
+      wait_a4<WS>(af[J]);
+      __builtin_amdgcn_s_barrier();
+      const unsigned char* sb = smem + J * STAGE;
+      bf16x8 xf[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + xro[n]);
+      issue(JN, af[JN]);
+      if (mul) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          if (kk == 1) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + (xro[n] ^ 64));
+          }
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[J][m][kk], xf[n], acc[m][n], 0, 0, 0);
+        }
+      }
+    };
+    using J0 = std::integral_constant<int, 0>;
+    using J1 = std::integral_constant<int, 1>;
+    using J2 = std::integral_constant<int, 2>;
+    using J3 = std::integral_constant<int, 3>;
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) issue(st, af[st]);     // nk >= NST - 1 (host)
+    const int full = nk / NST, rem = nk - full * NST;
+    for (int g = 0; g < full; ++g) {
+      step(J0{}, true);
+      step(J1{}, true);
+      if constexpr (NST >= 3) step(J2{}, true);
+      if constexpr (NST >= 4) step(J3{}, true);
+    }
+    if (rem) {                                                 // last, partial group: same steps, the padded ones skip the MFMAs
+      step(J0{}, true);
+      step(J1{}, rem > 1);
+      if constexpr (NST >= 3) step(J2{}, rem > 2);
+      if constexpr (NST >= 4) step(J3{}, false);
+    }
+    // the dummy stages still in flight write zeros into the ring: they must have landed before the epilogue reuses it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_nop 7" ::: "memory");
+    lds_barrier();                                             // every wave has read its last fragments: the ring is free
+    epi.template run<false, true>(a, acc, smem, row_dst, co0, tid);
+  }
+}
+
+template <int NT, int NST, int WPE, int WCNT = 0>
+int launch_gemm9(GemmArgs& a, hipStream_t st, int grid_cap) {
+  constexpr int BMP = 16 * NT;
+  a.tilesC = a.Co_pad / 128;
+  a.nblk = a.tilesC * cdiv(a.M, BMP);
+  size_t ring = (size_t)NST * BMP * ROWB;
+  size_t epi = (size_t)BMP * (128 * 2 + 16) + 4 * 2 * 128 * 4;
+  a.aux = (int)(ring > epi ? ring : epi);
+  size_t lds = (size_t)a.aux + BMP * 16 + 64;
+  auto k = conv_gemm9_kernel<NT, NST, WPE, WCNT>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  int grid = a.nblk;
+  if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+  return 0;
+}
+
+template <int NST, int WPE, int WCNT = 0>
+int launch_gemm9_nt(int nt, GemmArgs& a, hipStream_t st, int grid_cap) {
+  if (nt == 8) return launch_gemm9<8, NST, WPE, WCNT>(a, st, grid_cap);
+  if (nt == 6) return launch_gemm9<6, NST, WPE, WCNT>(a, st, grid_cap);
+  return launch_gemm9<4, NST, WPE, WCNT>(a, st, grid_cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2487,6 +2747,60 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
       if (ns6 == 4) launch_gemm6<2, 2, 4, 4, 4>(a, st); else launch_gemm6<2, 2, 4, 4, 3>(a, st);
       MGD_CHECK_LAUNCH("conv_gather_gemm(producer/consumer)");
       return MGD_OK;
+    }
+    {
+      // hand-counted pipeline (conv_gemm9_kernel): bf16 output, wave-uniform (tap, channel) per K-step
+      static int g9 = -1, g9nt = -1, g9grid = -1, g9nst = -1;
+      if (g9 < 0) {
+        const char* e = getenv("MGD_GEMM9"); g9 = e ? atoi(e) : 0;
+        e = getenv("MGD_GEMM9_NT"); g9nt = e ? atoi(e) : 0;
+        e = getenv("MGD_GEMM9_GRID"); g9grid = e ? atoi(e) : -1;      // -1: one block per slot (persistent); 0: one block per tile
+        (void)g9nst;
+      }
+      if (g9 && !d->dst_f32 && (d->ntaps == 1 || d->Ci % 64 == 0) && nk >= 2) {
+        int nt = g9nt;
+        if (nt != 8 && nt != 6 && nt != 4) {
+          // pixel tile that wastes least of the last round of 512 block slots (smaller tiles cost a little efficiency)
+          double best = 1e30;
+          const int cand[3] = {8, 6, 4};
+          const double pen[3] = {1.0, 1.04, 1.10};
+          const int nslots = 512;
+          for (int c = 0; c < 3; ++c) {
+            long long tiles = (long long)(d->Co_pad / 128) * cdiv(a.M, cand[c] * 16);
+            double rounds = (double)((tiles + nslots - 1) / nslots);
+            double cost = rounds * cand[c] * pen[c];
+            if (cost < best - 1e-9) { best = cost; nt = cand[c]; }
+          }
+        }
+        a.rowmask = a.colmask = 0;
+        for (int t = 0; t < d->ntaps; ++t) {
+          a.rowmask |= 1u << (9 * (d->dh[t] + 1) + t);
+          a.colmask |= 1u << (9 * (d->dw[t] + 1) + t);
+        }
+        // MGD_GEMM9: 1 = three stages in flight, two blocks per CU; 2 = four stages; 3 = two stages, three blocks per CU
+        const int slots = 512;
+        const int cap = g9grid < 0 ? slots : g9grid;
+        static int g9cnt = -1;
+        if (g9cnt < 0) { const char* e = getenv("MGD_GEMM9_CNT"); g9cnt = e ? atoi(e) : 0; }
+        // ring depth: MGD_GEMM9 = 1: the depth (3, 4 or 2) that pads the K-loop least (the loop runs whole groups of NST
+        // steps); 2 / 3 / 4: that depth where it applies (needs nk >= NST - 1)
+        int nst = g9 >= 2 && g9 <= 4 ? g9 : 0;
+        if (!nst) {
+          int bestpad = 1 << 30;
+          const int cand[3] = {3, 4, 2};
+          for (int c = 0; c < 3; ++c) {
+            const int pad = (nk + cand[c] - 1) / cand[c] * cand[c] - nk;
+            if (nk >= cand[c] - 1 && pad < bestpad) { bestpad = pad; nst = cand[c]; }
+          }
+        }
+        if (nst == 4 && nk < 3) nst = 3;
+        if (nst == 3 && nk < 2) nst = 2;
+        if (nst == 2) launch_gemm9_nt<2, 2>(nt, a, st, cap);
+        else if (nst == 4) { if (g9cnt) launch_gemm9_nt<4, 2, 1>(nt, a, st, cap); else launch_gemm9_nt<4, 2>(nt, a, st, cap); }
+        else { if (g9cnt) launch_gemm9_nt<3, 2, 1>(nt, a, st, cap); else launch_gemm9_nt<3, 2>(nt, a, st, cap); }
+        MGD_CHECK_LAUNCH("conv_gather_gemm(counted pipeline)");
+        return MGD_OK;
+      }
     }
     static int g8wc = -1;
     // four waves along the channels (32 x 128 wave tiles): every weight fragment is loaded by exactly one wave - with 2 x 2

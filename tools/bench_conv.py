@@ -73,9 +73,10 @@ def main():
         dw = torch.zeros(co, k * k, ci, device=dev)
         stats = torch.zeros(ops.STATS_REPLICAS, 2, co, device=dev)
         fl = 2.0 * B * ho * ho * k * k * ci * co
-        t_f = timeit(lambda: ops.conv_fwd(x, pk, out=y, stats=stats))
-        t_d = timeit(lambda: ops.conv_dgrad(dy, pk, (h, h), out=dx))
-        t_w = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s))
+        skip = os.environ.get("BENCH_SKIP", "")       # e.g. "wgrad" or "fwd,dgrad": passes not to time (reported as 1 us)
+        t_f = timeit(lambda: ops.conv_fwd(x, pk, out=y, stats=stats)) if "fwd" not in skip else 1.0
+        t_d = timeit(lambda: ops.conv_dgrad(dy, pk, (h, h), out=dx)) if "dgrad" not in skip else 1.0
+        t_w = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s)) if "wgrad" not in skip else 1.0
         by = 2.0 * (x.numel() + y.numel())
         print(f"{ci:5d} {co:5d} {k} {s} {h:4d} {n:2d} | {t_f:8.1f} {fl / t_f / 1e6:6.0f} {by / t_f / 1e3:6.0f} | "
               f"{t_d:8.1f} {fl / t_d / 1e6:6.0f} | {t_w:8.1f} {fl / t_w / 1e6:6.0f}", flush=True)
