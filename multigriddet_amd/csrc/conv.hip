@@ -77,6 +77,13 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
+// phase boundary of a hand-scheduled loop: hipcc may move neither MFMAs nor LDS reads across it
+__device__ __forceinline__ void phase_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  lds_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -560,6 +567,113 @@ struct GemmEpilogue {
     reduce_and_add(a, r1, r2, smem, co0, tid, stats, bnred);
   }
 
+  // The same epilogue in groups of G chunks per thread (EPC % G == 0): large tiles have 12 chunks per thread, and their
+  // HBM operands (12 + 12 uint4) beside the tile's values and offsets would not fit the register file.  HBM operands are
+  // fetched per group, after the accumulators have gone to LDS (the LATE form of run()).
+  template <int G>
+  __device__ __forceinline__ void run_grouped(const GemmArgs& a, f32x4 (&acc)[MT][NT], unsigned char* smem,
+                                              const long long* row_dst, int co0, int tid) {
+    static_assert(EPC % G == 0, "epilogue groups");
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / WP, wp = wave % WP;
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr int EROW = BNC * 2 + 16;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      int cl = (wc * MT + m) * 16 + fq * 4;
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      if (a.bias) {
+        int c = co0 + cl;
+        if (c + 3 < a.Co) { b0 = a.bias[c]; b1 = a.bias[c + 1]; b2 = a.bias[c + 2]; b3 = a.bias[c + 3]; }
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        int pl = (wp * NT + n) * 16 + fr;
+        f32x4 v = acc[m][n];
+        v[0] += b0; v[1] += b1; v[2] += b2; v[3] += b3;
+        if (a.act_slope != 0.f) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * a.act_slope;
+        }
+        uint2 p;
+        p.x = pack2bf(v[0], v[1]);
+        p.y = pack2bf(v[2], v[3]);
+        *(uint2*)(smem + pl * EROW + cl * 2) = p;
+      }
+    }
+    lds_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    bnred = a.bn_y != nullptr;
+    addpre = a.addend != nullptr;
+    const bool stats = a.stats != nullptr;
+    const int ch = tid % CPB;                        // NTHR % CPB == 0: the same 8 channels in every row this thread writes
+    const int c = co0 + ch * 8;
+    if (bnred) {
+      const float* ps[4] = {a.bn_scale, a.bn_shift, a.bn_mean, a.bn_invstd};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+        if (c < a.Co) { lo = *(const f32x4*)(ps[k] + c); hi = *(const f32x4*)(ps[k] + c + 4); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bnp[k][j] = lo[j]; bnp[k][4 + j] = hi[j]; }
+      }
+    }
+    float r1[8], r2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r1[j] = r2[j] = 0.f;
+#pragma unroll
+    for (int g0 = 0; g0 < EPC; g0 += G) {
+      long long offs[G];
+      uint4 vals[G], yv4[G], av4[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) offs[i] = row_dst[(tid + (g0 + i) * NTHR) / CPB];
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const int r = (tid + (g0 + i) * NTHR) / CPB;
+        vals[i] = *(const uint4*)(smem + r * EROW + ch * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const bool ok = offs[i] >= 0 && c < a.Co;
+        yv4[i] = (bnred && ok) ? *(const uint4*)(a.bn_y + offs[i] + c) : make_uint4(0, 0, 0, 0);
+        av4[i] = (addpre && ok) ? *(const uint4*)(a.addend + offs[i] + c) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const long long off = offs[i];
+        if (off < 0 || c >= a.Co) continue;
+        uint4 v = vals[i];
+        if (addpre) {
+          float f[8], g[8];
+          unpack8(v, f);
+          unpack8(av4[i], g);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] += g[j];
+          v = pack8(f);
+        }
+        *(uint4*)((bf16_t*)a.dst + off + c) = v;
+        if (stats) {
+          float d[8];
+          unpack8(v, d);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { r1[j] += d[j]; r2[j] = fmaf(d[j], d[j], r2[j]); }
+        } else if (bnred) {
+          float d[8], yv[8];
+          unpack8(v, d);
+          unpack8(yv4[i], yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float z = fmaf(yv[j], bnp[0][j], bnp[1][j]);
+            float dd = z > 0.f ? d[j] : d[j] * a.bn_slope;
+            r1[j] += dd;
+            r2[j] = fmaf(dd * (yv[j] - bnp[2][j]), bnp[3][j], r2[j]);
+          }
+        }
+      }
+    }
+    reduce_and_add(a, r1, r2, smem, co0, tid, stats, bnred);
+  }
+
   // one flush per block of a persistent kernel (all threads; smem = the epilogue region, free at this point)
   __device__ __forceinline__ void flush(const GemmArgs& a, unsigned char* smem, int co0, int tid) {
     const bool stats = a.stats != nullptr;
@@ -966,29 +1080,34 @@ __device__ __forceinline__ int sgpr(int v) {
 // Tile 128 channels x 16*NT pixels (NT = 8, 6, 4: the host picks the pixel tile that fills the 512 block slots best),
 // 4 waves of 32 channels x 16*NT pixels, NST-deep ring of pixel stages, NST register sets of weight fragments, 2 blocks
 // per CU (<= 256 registers).  Persistent: the grid is min(tiles, 512) and a block walks tiles blockIdx.x + i * gridDim.x.
-template <int XCH>
-__device__ __forceinline__ void dma_rows_asm(const unsigned (&voff)[XCH], i32x4 srd, unsigned lds_dst) {
+// XCH pixel pieces of one stage: piece i goes to LDS byte address lds_dst + i * STRIDE (wave-uniform; lane l lands at + 16 l).
+// M0 is the compiler's: saved, set and restored inside ONE statement.
+#define MGD_DMA_FIRST "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %2, 0 offen lds\n\t"
+#define MGD_DMA_NEXT(k) "s_add_u32 m0, m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %" #k ", %2, 0 offen lds\n\t"
+#define MGD_DMA_LAST "s_mov_b32 m0, %0"
+template <int XCH, int STRIDE>
+__device__ __forceinline__ void dma_rows_asm(const unsigned (&v)[XCH], i32x4 srd, unsigned lds_dst) {
   unsigned keep;
-  if constexpr (XCH == 4) {
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %6, 0 offen lds\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %6, 0 offen lds\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, 0 offen lds\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, 0 offen lds\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(lds_dst), "s"(srd) : "memory", "scc");
-  } else if constexpr (XCH == 3) {
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, 0 offen lds\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, 0 offen lds\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(lds_dst), "s"(srd) : "memory", "scc");
-  } else {
-    static_assert(XCH == 2, "pixel pieces per wave and stage");
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, 0 offen lds\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, 0 offen lds\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "s"(lds_dst), "s"(srd) : "memory", "scc");
-  }
+  static_assert(XCH >= 1 && XCH <= 6, "pixel pieces per wave and stage");
+  if constexpr (XCH == 1)
+    asm volatile(MGD_DMA_FIRST MGD_DMA_LAST : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]) : "memory", "scc");
+  else if constexpr (XCH == 2)
+    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_LAST
+                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]) : "memory", "scc");
+  else if constexpr (XCH == 3)
+    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_NEXT(6) MGD_DMA_LAST
+                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]), "v"(v[2]) : "memory", "scc");
+  else if constexpr (XCH == 4)
+    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_NEXT(6) MGD_DMA_NEXT(7) MGD_DMA_LAST
+                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory", "scc");
+  else if constexpr (XCH == 5)
+    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_NEXT(6) MGD_DMA_NEXT(7) MGD_DMA_NEXT(8) MGD_DMA_LAST
+                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4])
+                 : "memory", "scc");
+  else
+    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_NEXT(6) MGD_DMA_NEXT(7) MGD_DMA_NEXT(8) MGD_DMA_NEXT(9) MGD_DMA_LAST
+                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5])
+                 : "memory", "scc");
 }
 
 // the four weight fragments of a K-step (2 channel groups x 2 k-halves), 1 KiB apart in the fragment-ordered image
@@ -1004,13 +1123,15 @@ __device__ __forceinline__ void wait_a4(bf16x8 (&f)[2][2]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]) : "n"(N) : "memory");
 }
 
-template <int NT, int NST, int WPE, int WCNT = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void conv_gemm9_kernel(GemmArgs a) {
-  constexpr int WC = 4, WP = 1, MT = 2, BNC = 128, BMP = 16 * NT, NTHR = 256;
-  constexpr int RPR = NTHR / 8, XCH = BMP / RPR;           // 32 rows per DMA round; 4 / 3 / 2 pixel pieces per wave and stage
+template <int WC, int NT, int NST, bool PP = false>
+__global__ __launch_bounds__(64 * WC) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_gemm9_kernel(GemmArgs a) {
+  constexpr int WP = 1, MT = 2, BNC = 32 * WC, BMP = 16 * NT, NTHR = 64 * WC;
+  constexpr int RPR = NTHR / 8, XCH = BMP / RPR;           // rows per DMA round of the block; pixel pieces per wave and stage
+  static_assert(BMP % RPR == 0, "pixel tile must be whole DMA rounds");
   constexpr int STAGE = BMP * ROWB;
   constexpr int GRP = 4 + XCH;                              // vector-memory instructions per stage and wave
-  static_assert(NST >= 2 && NST <= 4, "ring depth");
+  static_assert(NST >= 2 && NST <= 5 && (!PP || (NST >= 3 && WC == 8)), "ring depth");
+  constexpr int DIST = NST - 1 - (PP ? 1 : 0);              // stages between the one being multiplied and the one being issued
   using Epi = GemmEpilogue<WC, WP, MT, NT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   long long* row_dst = (long long*)(smem + a.aux);
@@ -1088,7 +1209,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     };
     int s_toff = tap_off(0);
     // weight fragments of (tile tc, K-step ks): 16 KiB, this wave's four fragments start at wave * 4 KiB
-    const char* abase = (const char*)a.wpk + ((size_t)tc * nk * 16 + (size_t)wave * 4) * 1024;
+    // (a block of 8 waves spans two consecutive 128-row tiles of the image)
+    const char* abase = (const char*)a.wpk + ((size_t)(tc * (WC / 4) + (wave >> 2)) * nk * 16 + (size_t)(wave & 3) * 4) * 1024;
     int s_issued = 0;
     // Issues the next stage.  Past the last K-step it issues a DUMMY stage instead - every pixel lane out of range (no memory
     // traffic, zeros into a ring slot nobody reads again), the weight fragments of the last step once more - so that every
@@ -1100,7 +1222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       unsigned vo[XCH];
 #pragma unroll
       for (int i = 0; i < XCH; ++i) vo[i] = ((vmask[i] & bit) && kin) ? xoff[i] + (unsigned)s_toff : OOB;
-      dma_rows_asm<XCH>(vo, srd, lds0 + buf * STAGE);
+      dma_rows_asm<XCH, RPR * ROWB>(vo, srd, lds0 + buf * STAGE);
       load_a4_asm(f, lane16, abase + (size_t)min(s_issued, nk - 1) * 16384);
       ++s_issued;
       if (real) {
@@ -1124,73 +1246,142 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     // set that is still in flight must never pass through a compiler-made copy (a v_mov of a pending load destination reads
     // garbage) - 'if' ladders around the waits and a 'break' inside the unrolled body both made hipcc merge differently
     // allocated copies of the sets in front of the wait.
-    // LDS-DMA and register loads are not known to return in order with respect to each other: a count proves "the oldest
-    // stage has landed" only when the survivors of EITHER kind must belong to younger stages, i.e. min(DMA, register loads)
-    // per stage in flight (WCNT = 1, MGD_GEMM9_CNT=1: the full group count, for the A/B measurement)
-    constexpr int SAFE = WCNT ? GRP : (XCH < 4 ? XCH : 4);
-    constexpr int WS = (NST - 2) * SAFE;
+    // vmcnt counts LDS-DMA and register loads together, but the two kinds do NOT retire in issue order with respect to
+    // each other (measured: 2 DMA + 4 register loads per stage, a wait for all but the 6 youngest let a multiply read a
+    // stage whose DMA had not landed - the younger register loads had overtaken it).  Each kind does retire in order, so a
+    // count proves "the older stage is complete" as long as the survivors of EITHER kind alone must all be younger: at
+    // most min(DMA, register loads) per stage left in flight.
+    constexpr int SAFE = XCH < 4 ? XCH : 4;
+    constexpr int WS = (DIST - 1) * SAFE;                      // steady state: what may stay in flight behind the wait
+    auto mults = [&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const unsigned char* sb = smem + J * STAGE;
+      // pixel fragments in groups of NH tiles (all of them up to 128 pixels; halves of a 192-pixel tile, whose 12 + 12
+      // fragments beside 96 accumulators and the weight sets would spill); group (0, 0) was read by the caller
+      constexpr int NH = NT > 8 ? NT / 2 : NT;
+      return [&, sb](bf16x8 (&xf)[NH]) {
+#pragma unroll
+        for (int h = 0; h < NT / NH; ++h)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            if (h + kk) {
+#pragma unroll
+              for (int n = 0; n < NH; ++n) xf[n] = *(const bf16x8*)(sb + (xro[h * NH + n] ^ (kk << 6)));
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int n = 0; n < NH; ++n)
+                acc[m][h * NH + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[J][m][kk], xf[n], acc[m][h * NH + n], 0, 0, 0);
+          }
+      };
+    };
+    constexpr int NH = NT > 8 ? NT / 2 : NT;
+    // One K-step on register set / ring stage J (compile-time).  No branch lies between a load and its wait: a register
+    // set that is still in flight must never pass through a compiler-made copy (a v_mov of a pending load destination
+    // reads garbage) - 'if' ladders around the waits and a 'break' inside the unrolled body both made hipcc merge
+    // differently allocated copies of the sets in front of the wait.  mul: the padded steps of the last group only keep
+    // the pipeline's count.
     auto step = [&](auto jc, bool mul) {
       constexpr int J = decltype(jc)::value;
-      constexpr int JN = (J + NST - 1) % NST;
+      constexpr int JN = (J + DIST) % NST;
       wait_a4<WS>(af[J]);
       __builtin_amdgcn_s_barrier();
       const unsigned char* sb = smem + J * STAGE;
-      bf16x8 xf[NT];
+      bf16x8 xf[NH];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + xro[n]);
+      for (int n = 0; n < NH; ++n) xf[n] = *(const bf16x8*)(sb + xro[n]);
       issue(JN, af[JN]);
-      if (mul) {
+      if (mul) mults(jc)(xf);
+    };
+    // Ping-pong form (8 waves, two per SIMD): waves 4-7 run one phase behind waves 0-3, so that on every SIMD one wave
+    // multiplies while its partner reads fragments and issues the next stage - the two never want the matrix pipe at once,
+    // and each wave's memory phase hides under the other's MFMAs.  Two barriers per K-step separate the phases:
+    //   waves 0-3:  [read s, issue s+DIST] | [multiply s, wait s+1] | [read s+1, issue] | ...
+    //   waves 4-7:        (idle)           | [read s, issue, wait s+1] | [multiply s]   | ...
+    // Stage s+1 must have landed, for every wave, before the phase in which waves 0-3 read it: both groups wait for it in
+    // the phase before.  A stage is read during two phases, so the ring has one more slot than stages in flight + 1.
+    auto step_a = [&](auto jc, bool mul) {
+      constexpr int J = decltype(jc)::value;
+      constexpr int JN = (J + DIST) % NST, J1 = (J + 1) % NST;
+      const unsigned char* sb = smem + J * STAGE;
+      bf16x8 xf[NH];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          if (kk == 1) {
+      for (int n = 0; n < NH; ++n) xf[n] = *(const bf16x8*)(sb + xro[n]);
+      issue(JN, af[JN]);
+      phase_barrier();
+      if (mul) mults(jc)(xf);
+      wait_a4<WS>(af[J1]);
+      phase_barrier();
+    };
+    auto step_b = [&](auto jc, bool mul) {
+      constexpr int J = decltype(jc)::value;
+      constexpr int JN = (J + DIST) % NST, J1 = (J + 1) % NST;
+      const unsigned char* sb = smem + J * STAGE;
+      bf16x8 xf[NH];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + (xro[n] ^ 64));
-          }
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[J][m][kk], xf[n], acc[m][n], 0, 0, 0);
-        }
-      }
+      for (int n = 0; n < NH; ++n) xf[n] = *(const bf16x8*)(sb + xro[n]);
+      issue(JN, af[JN]);
+      wait_a4<WS>(af[J1]);
+      phase_barrier();
+      if (mul) mults(jc)(xf);
+      phase_barrier();
     };
     using J0 = std::integral_constant<int, 0>;
-    using J1 = std::integral_constant<int, 1>;
+    using J1_ = std::integral_constant<int, 1>;
     using J2 = std::integral_constant<int, 2>;
     using J3 = std::integral_constant<int, 3>;
+    using J4 = std::integral_constant<int, 4>;
 #pragma unroll
-    for (int st = 0; st < NST - 1; ++st) issue(st, af[st]);     // nk >= NST - 1 (host)
+    for (int st = 0; st < DIST; ++st) issue(st, af[st]);        // nk >= DIST (host)
     const int full = nk / NST, rem = nk - full * NST;
-    for (int g = 0; g < full; ++g) {
-      step(J0{}, true);
-      step(J1{}, true);
-      if constexpr (NST >= 3) step(J2{}, true);
-      if constexpr (NST >= 4) step(J3{}, true);
-    }
-    if (rem) {                                                 // last, partial group: same steps, the padded ones skip the MFMAs
-      step(J0{}, true);
-      step(J1{}, rem > 1);
-      if constexpr (NST >= 3) step(J2{}, rem > 2);
-      if constexpr (NST >= 4) step(J3{}, false);
+    auto run_steps = [&](auto&& stp) {
+      for (int g = 0; g < full; ++g) {
+        stp(J0{}, true);
+        stp(J1_{}, true);
+        if constexpr (NST >= 3) stp(J2{}, true);
+        if constexpr (NST >= 4) stp(J3{}, true);
+        if constexpr (NST >= 5) stp(J4{}, true);
+      }
+      if (rem) {                                               // last, partial group: same steps, the padded ones skip the MFMAs
+        stp(J0{}, true);
+        stp(J1_{}, rem > 1);
+        if constexpr (NST >= 3) stp(J2{}, rem > 2);
+        if constexpr (NST >= 4) stp(J3{}, rem > 3);
+        if constexpr (NST >= 5) stp(J4{}, false);
+      }
+    };
+    if constexpr (PP) {
+      wait_a4<WS>(af[0]);
+      phase_barrier();
+      if (wave >= WC / 2) {
+        phase_barrier();
+        run_steps(step_b);
+      } else {
+        run_steps(step_a);
+        phase_barrier();
+      }
+    } else {
+      run_steps(step);
     }
     // the dummy stages still in flight write zeros into the ring: they must have landed before the epilogue reuses it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_nop 7" ::: "memory");
     lds_barrier();                                             // every wave has read its last fragments: the ring is free
-    epi.template run<false, true>(a, acc, smem, row_dst, co0, tid);
+    epi.template run_grouped<(Epi::EPC > 8 ? Epi::EPC / 2 : Epi::EPC)>(a, acc, smem, row_dst, co0, tid);
   }
 }
 
-template <int NT, int NST, int WPE, int WCNT = 0>
+template <int WC, int NT, int NST, bool PP = false>
 int launch_gemm9(GemmArgs& a, hipStream_t st, int grid_cap) {
-  constexpr int BMP = 16 * NT;
-  a.tilesC = a.Co_pad / 128;
+  constexpr int BMP = 16 * NT, BNC = 32 * WC;
+  a.tilesC = a.Co_pad / BNC;
   a.nblk = a.tilesC * cdiv(a.M, BMP);
   size_t ring = (size_t)NST * BMP * ROWB;
-  size_t epi = (size_t)BMP * (128 * 2 + 16) + 4 * 2 * 128 * 4;
+  size_t epi = (size_t)BMP * (BNC * 2 + 16) + (size_t)WC * 2 * BNC * 4;
   a.aux = (int)(ring > epi ? ring : epi);
   size_t lds = (size_t)a.aux + BMP * 16 + 64;
-  auto k = conv_gemm9_kernel<NT, NST, WPE, WCNT>;
+  auto k = conv_gemm9_kernel<WC, NT, NST, PP>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1198,15 +1389,22 @@ int launch_gemm9(GemmArgs& a, hipStream_t st, int grid_cap) {
   }
   int grid = a.nblk;
   if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WC), lds, st, a);
   return 0;
 }
 
-template <int NST, int WPE, int WCNT = 0>
-int launch_gemm9_nt(int nt, GemmArgs& a, hipStream_t st, int grid_cap) {
-  if (nt == 8) return launch_gemm9<8, NST, WPE, WCNT>(a, st, grid_cap);
-  if (nt == 6) return launch_gemm9<6, NST, WPE, WCNT>(a, st, grid_cap);
-  return launch_gemm9<4, NST, WPE, WCNT>(a, st, grid_cap);
+// (WC, NT) -> instance; the 8-wave form needs whole DMA rounds of 64 rows: NT = 4, 8, 12
+template <int NST>
+int launch_gemm9_cfg(int wc, int nt, GemmArgs& a, hipStream_t st, int grid_cap) {
+  if (wc == 8) {
+    if (nt == 12) return launch_gemm9<8, 12, NST>(a, st, grid_cap);
+    if (nt == 8) return launch_gemm9<8, 8, NST>(a, st, grid_cap);
+    return launch_gemm9<8, 4, NST>(a, st, grid_cap);
+  }
+  if (nt == 12) return launch_gemm9<4, 12, NST>(a, st, grid_cap);
+  if (nt == 8) return launch_gemm9<4, 8, NST>(a, st, grid_cap);
+  if (nt == 6) return launch_gemm9<4, 6, NST>(a, st, grid_cap);
+  return launch_gemm9<4, 4, NST>(a, st, grid_cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2750,38 +2948,45 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     }
     {
       // hand-counted pipeline (conv_gemm9_kernel): bf16 output, wave-uniform (tap, channel) per K-step
-      static int g9 = -1, g9nt = -1, g9grid = -1, g9nst = -1;
+      static int g9 = -1, g9nt = -1, g9wc = -1, g9grid = -1, g9cnt = -1, g9one = -1;
       if (g9 < 0) {
         const char* e = getenv("MGD_GEMM9"); g9 = e ? atoi(e) : 0;
         e = getenv("MGD_GEMM9_NT"); g9nt = e ? atoi(e) : 0;
+        e = getenv("MGD_GEMM9_WC"); g9wc = e ? atoi(e) : 0;
         e = getenv("MGD_GEMM9_GRID"); g9grid = e ? atoi(e) : -1;      // -1: one block per slot (persistent); 0: one block per tile
-        (void)g9nst;
+        e = getenv("MGD_GEMM9_CNT"); g9cnt = e ? atoi(e) : 1;
+        e = getenv("MGD_GEMM9_1X1"); g9one = e ? atoi(e) : 0;         // 1: also the 1x1 convolutions
       }
-      if (g9 && !d->dst_f32 && (d->ntaps == 1 || d->Ci % 64 == 0) && nk >= 2) {
-        int nt = g9nt;
-        if (nt != 8 && nt != 6 && nt != 4) {
-          // pixel tile that wastes least of the last round of 512 block slots (smaller tiles cost a little efficiency)
+      if (g9 && !d->dst_f32 && ((d->ntaps == 1 && g9one) || (d->ntaps > 1 && d->Ci % 64 == 0)) && nk >= 2) {
+        // Tile shape.  The K-loop is bound by the CU's vector-memory path (~25 B/clk delivered, weights + pixels), so the
+        // cost of a launch is modelled as rounds x K-steps x bytes per step of the resident blocks of a CU; wider tiles move
+        // fewer bytes per FLOP but quantise worse on 256 CUs.  8 waves x 256 channels: one block per CU; 4 waves x 128
+        // channels: two.
+        int wc = 4, nt = 8;
+        {
           double best = 1e30;
-          const int cand[3] = {8, 6, 4};
-          const double pen[3] = {1.0, 1.04, 1.10};
-          const int nslots = 512;
-          for (int c = 0; c < 3; ++c) {
-            long long tiles = (long long)(d->Co_pad / 128) * cdiv(a.M, cand[c] * 16);
-            double rounds = (double)((tiles + nslots - 1) / nslots);
-            double cost = rounds * cand[c] * pen[c];
-            if (cost < best - 1e-9) { best = cost; nt = cand[c]; }
+          const int cw[7] = {8, 8, 8, 4, 4, 4, 4}, cn[7] = {12, 8, 4, 12, 8, 6, 4};
+          for (int c = 0; c < 7; ++c) {
+            if (g9wc && cw[c] != g9wc) continue;
+            if (g9nt && cn[c] != g9nt) continue;
+            if (cw[c] == 8 && d->Co_pad % 256) continue;
+            const int slots = cw[c] == 8 ? 256 : 512, per_cu = cw[c] == 8 ? 1 : 2;
+            const long long tiles = (long long)(d->Co_pad / (32 * cw[c])) * cdiv(a.M, cn[c] * 16);
+            const double rounds = (double)((tiles + slots - 1) / slots);
+            const double bytes = per_cu * (cw[c] * 4096.0 + cn[c] * 16 * 128.0);      // per K-step and CU
+            const double mfma = 2.0 * cn[c] * 2 * 16 * 2 * 1.6;                        // cycles per K-step and SIMD at 2 waves, derated
+            const double cost = rounds * (bytes / 25.0 > mfma ? bytes / 25.0 : mfma) + rounds * 600.0;   // + epilogue / prologue per round
+            if (cost < best - 1e-9) { best = cost; wc = cw[c]; nt = cn[c]; }
           }
+          if (best > 9e29) { wc = 4; nt = 8; }
         }
         a.rowmask = a.colmask = 0;
         for (int t = 0; t < d->ntaps; ++t) {
           a.rowmask |= 1u << (9 * (d->dh[t] + 1) + t);
           a.colmask |= 1u << (9 * (d->dw[t] + 1) + t);
         }
-        // MGD_GEMM9: 1 = three stages in flight, two blocks per CU; 2 = four stages; 3 = two stages, three blocks per CU
-        const int slots = 512;
+        const int slots = wc == 8 ? 256 : 512;
         const int cap = g9grid < 0 ? slots : g9grid;
-        static int g9cnt = -1;
-        if (g9cnt < 0) { const char* e = getenv("MGD_GEMM9_CNT"); g9cnt = e ? atoi(e) : 0; }
         // ring depth: MGD_GEMM9 = 1: the depth (3, 4 or 2) that pads the K-loop least (the loop runs whole groups of NST
         // steps); 2 / 3 / 4: that depth where it applies (needs nk >= NST - 1)
         int nst = g9 >= 2 && g9 <= 4 ? g9 : 0;
@@ -2793,11 +2998,22 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
             if (nk >= cand[c] - 1 && pad < bestpad) { bestpad = pad; nst = cand[c]; }
           }
         }
-        if (nst == 4 && nk < 3) nst = 3;
+        if (nst == 4 && (nk < 3 || (wc == 4 && nt == 12))) nst = 3;      // four stages of 192 pixels: two blocks would not fit a CU
         if (nst == 3 && nk < 2) nst = 2;
-        if (nst == 2) launch_gemm9_nt<2, 2>(nt, a, st, cap);
-        else if (nst == 4) { if (g9cnt) launch_gemm9_nt<4, 2, 1>(nt, a, st, cap); else launch_gemm9_nt<4, 2>(nt, a, st, cap); }
-        else { if (g9cnt) launch_gemm9_nt<3, 2, 1>(nt, a, st, cap); else launch_gemm9_nt<3, 2>(nt, a, st, cap); }
+        (void)g9cnt;
+        static int g9pp = -1;
+        if (g9pp < 0) { const char* e = getenv("MGD_GEMM9_PP"); g9pp = e ? atoi(e) : 0; }
+        if (g9pp && wc == 8 && (nt == 8 || nt == 12) && nk >= 3) {
+          // ping-pong form: g9pp = ring slots (3: one stage in flight, 4: two); default the one that pads the K-loop less
+          int nb = g9pp == 3 || g9pp == 4 ? g9pp : ((nk % 4 == 0 || (nk % 3 && nk % 4 >= nk % 3)) ? 4 : 3);
+          if (nt == 8) { if (nb == 4) launch_gemm9<8, 8, 4, true>(a, st, cap); else launch_gemm9<8, 8, 3, true>(a, st, cap); }
+          else { if (nb == 4) launch_gemm9<8, 12, 4, true>(a, st, cap); else launch_gemm9<8, 12, 3, true>(a, st, cap); }
+          MGD_CHECK_LAUNCH("conv_gather_gemm(counted pipeline, ping-pong)");
+          return MGD_OK;
+        }
+        if (nst == 2) launch_gemm9_cfg<2>(wc, nt, a, st, cap);
+        else if (nst == 4) launch_gemm9_cfg<4>(wc, nt, a, st, cap);
+        else launch_gemm9_cfg<3>(wc, nt, a, st, cap);
         MGD_CHECK_LAUNCH("conv_gather_gemm(counted pipeline)");
         return MGD_OK;
       }
