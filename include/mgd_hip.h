@@ -33,6 +33,10 @@ extern "C" {
 const char* mgd_last_error(void);
 int mgd_version(void);
 
+/* Diagnostic only (tools/stamp_gemm9.py): reads and clears the 3 x 8 phase-time accumulators of the stamped build of the
+ * gather-GEMM (MGD_DBG=4096).  No reference counterpart. */
+int mgd_debug_stamps(unsigned long long* out24);
+
 /* ----------------------------------------------------------------------------------------------
  * Convolution engine (implicit GEMM on bf16 MFMA, fp32 accumulate).
  * Replaces: Keras Conv2D as used by DarknetConv2D / DarknetConv2D_BN_Leaky

@@ -1082,7 +1082,7 @@ __device__ __forceinline__ int sgpr(int v) {
 // per CU (<= 256 registers).  Persistent: the grid is min(tiles, 512) and a block walks tiles blockIdx.x + i * gridDim.x.
 // XCH pixel pieces of one stage: piece i goes to LDS byte address lds_dst + i * STRIDE (wave-uniform; lane l lands at + 16 l).
 // M0 is the compiler's: saved, set and restored inside ONE statement.
-#define MGD_DMA_FIRST "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %2, 0 offen lds\n\t"
+#define MGD_DMA_FIRST "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %2, 0 offen lds\n\t"
 #define MGD_DMA_NEXT(k) "s_add_u32 m0, m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %" #k ", %2, 0 offen lds\n\t"
 #define MGD_DMA_LAST "s_mov_b32 m0, %0"
 template <int XCH, int STRIDE>
@@ -1111,8 +1111,11 @@ __device__ __forceinline__ void dma_rows_asm(const unsigned (&v)[XCH], i32x4 srd
 }
 
 // the four weight fragments of a K-step (2 channel groups x 2 k-halves), 1 KiB apart in the fragment-ordered image
+// (s_nop 4: the base may come straight from v_readfirstlane - a VALU write of an SGPR needs five wait states before a
+// vector-memory instruction reads it as an address, and hipcc pads nothing inside an asm statement; without it the loads of
+// conv_gemm10_kernel used a stale SGPR pair now and then: memory access faults that came and went with the launch size)
 __device__ __forceinline__ void load_a4_asm(bf16x8 (&f)[2][2], unsigned lane16, const void* sbase) {
-  asm volatile("global_load_dwordx4 %0, %4, %5 offset:0\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5 offset:0\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
                "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"
                : "=&v"(f[0][0]), "=&v"(f[0][1]), "=&v"(f[1][0]), "=&v"(f[1][1]) : "v"(lane16), "s"(sbase) : "memory");
 }
@@ -1123,14 +1126,18 @@ __device__ __forceinline__ void wait_a4(bf16x8 (&f)[2][2]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]) : "n"(N) : "memory");
 }
 
-template <int WC, int NT, int NST, bool PP = false>
+// diagnostic build (STAMP): per-phase s_memtime deltas of waves 0 and WC/2 of every block, summed into g_stamps[group][8]
+// (+ a step count in slot 7); read and reset through mgd_debug_stamps().  Never instantiated on the product path.
+__device__ unsigned long long g_stamps[3][8];      // [2]: per tile - tables, prologue issue, first wait, K-loop, drain, epilogue, tiles
+
+template <int WC, int NT, int NST, bool PP = false, bool STAMP = false>
 __global__ __launch_bounds__(64 * WC) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_gemm9_kernel(GemmArgs a) {
   constexpr int WP = 1, MT = 2, BNC = 32 * WC, BMP = 16 * NT, NTHR = 64 * WC;
   constexpr int RPR = NTHR / 8, XCH = BMP / RPR;           // rows per DMA round of the block; pixel pieces per wave and stage
   static_assert(BMP % RPR == 0, "pixel tile must be whole DMA rounds");
   constexpr int STAGE = BMP * ROWB;
   constexpr int GRP = 4 + XCH;                              // vector-memory instructions per stage and wave
-  static_assert(NST >= 2 && NST <= 5 && (!PP || (NST >= 3 && WC == 8)), "ring depth");
+  static_assert(NST >= 2 && NST <= 5 && (!PP || (NST == 4 && WC == 8)), "ring depth");
   constexpr int DIST = NST - 1 - (PP ? 1 : 0);              // stages between the one being multiplied and the one being issued
   using Epi = GemmEpilogue<WC, WP, MT, NT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1161,8 +1168,10 @@ __global__ __launch_bounds__(64 * WC) __attribute__((amdgpu_waves_per_eu(2, 2)))
   for (int n = 0; n < NT; ++n) xro[n] = lds_off(n * 16 + fr, fq);
   const unsigned lane16 = lane * 16;
 
+  unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // STAMP only
   for (int t = blockIdx.x; t < a.nblk; t += gridDim.x) {
     Epi epi;                                                   // per tile: none of its registers lives across the K-loop
+    const unsigned long long tt0 = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
     const int L = xcd_remap(t, a.nblk);
     const int tc = L % a.tilesC, tp = L / a.tilesC;
     const int co0 = tc * BNC, pix0 = tp * BMP;
@@ -1297,43 +1306,48 @@ __global__ __launch_bounds__(64 * WC) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // Ping-pong form (8 waves, two per SIMD): waves 4-7 run one phase behind waves 0-3, so that on every SIMD one wave
     // multiplies while its partner reads fragments and issues the next stage - the two never want the matrix pipe at once,
     // and each wave's memory phase hides under the other's MFMAs.  Two barriers per K-step separate the phases:
-    //   waves 0-3:  [read s, issue s+DIST] | [multiply s, wait s+1] | [read s+1, issue] | ...
-    //   waves 4-7:        (idle)           | [read s, issue, wait s+1] | [multiply s]   | ...
-    // Stage s+1 must have landed, for every wave, before the phase in which waves 0-3 read it: both groups wait for it in
-    // the phase before.  A stage is read during two phases, so the ring has one more slot than stages in flight + 1.
-    auto step_a = [&](auto jc, bool mul) {
+    //   waves 0-3:  [wait s+1, read s, issue s+2] | [multiply s]              | [wait s+2, read s+1, issue s+3] | ...
+    //   waves 4-7:        (one barrier behind)    | [wait s+1, read s, issue] | [multiply s]                    | ...
+    // A stage is issued in step s, waited for at the start of step s+1 - a whole step later, by every wave, with nothing
+    // else in flight: vmcnt(0), so the order in which LDS-DMA and register loads retire does not matter - and read in step
+    // s+2, one phase after the last wave's wait.  A stage is read during three phases (waves 0-3: one, waves 4-7: two, the
+    // second k-half inside their multiply phase), hence four ring slots for two stages in flight.
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long { return STAMP ? __builtin_amdgcn_s_memtime() : 0ull; };
+    auto step_pp = [&](auto jc, bool mul) {
       constexpr int J = decltype(jc)::value;
       constexpr int JN = (J + DIST) % NST, J1 = (J + 1) % NST;
       const unsigned char* sb = smem + J * STAGE;
+      const unsigned long long t0 = now();
+      wait_a4<0>(af[J1]);
+      const unsigned long long t1 = now();
       bf16x8 xf[NH];
 #pragma unroll
       for (int n = 0; n < NH; ++n) xf[n] = *(const bf16x8*)(sb + xro[n]);
+      const unsigned long long t2 = now();
       issue(JN, af[JN]);
+      const unsigned long long t3 = now();
       phase_barrier();
+      const unsigned long long t4 = now();
       if (mul) mults(jc)(xf);
-      wait_a4<WS>(af[J1]);
+      const unsigned long long t5 = now();
       phase_barrier();
-    };
-    auto step_b = [&](auto jc, bool mul) {
-      constexpr int J = decltype(jc)::value;
-      constexpr int JN = (J + DIST) % NST, J1 = (J + 1) % NST;
-      const unsigned char* sb = smem + J * STAGE;
-      bf16x8 xf[NH];
-#pragma unroll
-      for (int n = 0; n < NH; ++n) xf[n] = *(const bf16x8*)(sb + xro[n]);
-      issue(JN, af[JN]);
-      wait_a4<WS>(af[J1]);
-      phase_barrier();
-      if (mul) mults(jc)(xf);
-      phase_barrier();
+      if (STAMP) {
+        const unsigned long long t6 = now();
+        st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2; st_acc[3] += t4 - t3; st_acc[4] += t5 - t4;
+        st_acc[5] += t6 - t5; st_acc[7] += 1;
+      }
     };
     using J0 = std::integral_constant<int, 0>;
     using J1_ = std::integral_constant<int, 1>;
     using J2 = std::integral_constant<int, 2>;
     using J3 = std::integral_constant<int, 3>;
     using J4 = std::integral_constant<int, 4>;
+    const unsigned long long tt1 = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
 #pragma unroll
     for (int st = 0; st < DIST; ++st) issue(st, af[st]);        // nk >= DIST (host)
+    const unsigned long long tt2 = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long tt3 = 0;
     const int full = nk / NST, rem = nk - full * NST;
     auto run_steps = [&](auto&& stp) {
       for (int g = 0; g < full; ++g) {
@@ -1352,27 +1366,48 @@ __global__ __launch_bounds__(64 * WC) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     };
     if constexpr (PP) {
-      wait_a4<WS>(af[0]);
+      static_assert(!PP || (DIST == 2 && NST == 4), "ping-pong form: two stages in flight, four ring slots");
+      wait_a4<0>(af[0]);
+      tt3 = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
       phase_barrier();
       if (wave >= WC / 2) {
         phase_barrier();
-        run_steps(step_b);
+        run_steps(step_pp);
       } else {
-        run_steps(step_a);
+        run_steps(step_pp);
         phase_barrier();
       }
     } else {
       run_steps(step);
     }
+    if (STAMP) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ph_acc[q] += st_acc[q];
+    }
+    const unsigned long long tt4 = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
     // the dummy stages still in flight write zeros into the ring: they must have landed before the epilogue reuses it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_nop 7" ::: "memory");
     lds_barrier();                                             // every wave has read its last fragments: the ring is free
+    const unsigned long long tt5 = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
     epi.template run_grouped<(Epi::EPC > 8 ? Epi::EPC / 2 : Epi::EPC)>(a, acc, smem, row_dst, co0, tid);
+    if (STAMP) {
+      const unsigned long long tt6 = __builtin_amdgcn_s_memtime();
+      tl_acc[0] += tt1 - tt0; tl_acc[1] += tt2 - tt1; tl_acc[2] += tt3 - tt2; tl_acc[3] += tt4 - tt3; tl_acc[4] += tt5 - tt4;
+      tl_acc[5] += tt6 - tt5; tl_acc[7] += 1;
+    }
+  }
+  if (STAMP && PP && lane == 0 && (wave == 0 || wave == WC / 2)) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) atomicAdd(&g_stamps[wave ? 1 : 0][q], ph_acc[q]);
+    if (wave == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) atomicAdd(&g_stamps[2][q], tl_acc[q]);
+    }
   }
 }
 
-template <int WC, int NT, int NST, bool PP = false>
+template <int WC, int NT, int NST, bool PP = false, bool STAMP = false>
 int launch_gemm9(GemmArgs& a, hipStream_t st, int grid_cap) {
   constexpr int BMP = 16 * NT, BNC = 32 * WC;
   a.tilesC = a.Co_pad / BNC;
@@ -1381,7 +1416,7 @@ int launch_gemm9(GemmArgs& a, hipStream_t st, int grid_cap) {
   size_t epi = (size_t)BMP * (BNC * 2 + 16) + (size_t)WC * 2 * BNC * 4;
   a.aux = (int)(ring > epi ? ring : epi);
   size_t lds = (size_t)a.aux + BMP * 16 + 64;
-  auto k = conv_gemm9_kernel<WC, NT, NST, PP>;
+  auto k = conv_gemm9_kernel<WC, NT, NST, PP, STAMP>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1405,6 +1440,363 @@ int launch_gemm9_cfg(int wc, int nt, GemmArgs& a, hipStream_t st, int grid_cap) 
   if (nt == 8) return launch_gemm9<4, 8, NST>(a, st, grid_cap);
   if (nt == 6) return launch_gemm9<4, 6, NST>(a, st, grid_cap);
   return launch_gemm9<4, 4, NST>(a, st, grid_cap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming ping-pong gather-GEMM (round 3): 8 waves, block tile 256 channels x 128 pixels, one persistent block per CU.
+// What the stamped build of conv_gemm9_kernel showed for an 18-step tile (128 -> 256 at 76 x 76): K-loop 68 % of the tile's
+// time, epilogue 18 % (LDS round trip, five barriers, every CU storing at once), row tables + first loads 13 % - and in the
+// K-loop a wave that waited on a count right behind its own issue, and 10 % padded steps.  This kernel keeps the ping-pong
+// K-step (waves 4-7 one phase behind waves 0-3: on every SIMD one wave multiplies while its partner reads fragments and
+// issues the next stage) and removes the rest:
+//  * the ring never drains between tiles: a block's tiles form ONE stream of stages (6 slots, 3 register sets of weight
+//    fragments, a stage is issued in step s, waited for with vmcnt(0) at the start of step s+1 - a whole step later, so the
+//    order in which LDS-DMA and register loads retire does not matter - and read in step s+2); the first stages of tile
+//    t+1 go out during the last two steps of tile t.  K-loops run whole groups of 6 steps (host: nk % 6 == 0);
+//  * row tables (destination offset, source offset, tap mask per pixel) of tile t+1 are written while tile t multiplies
+//    (two table buffers in LDS);
+//  * the epilogue needs no LDS and no barrier: accumulators -> bf16 -> one v_permlane16_swap per dword pairs the two
+//    16-channel tiles of a wave so that every lane owns 8 consecutive channels (16 bytes) of one pixel -> global stores,
+//    executed at the start of the NEXT tile's first step, right behind its wait, so that the stores have a whole step to
+//    be acknowledged before the wave waits on vmcnt again; BatchNorm sums / fused BN-backward sums stay in registers
+//    across the tiles of a block and are reduced (DPP over the 16 pixel lanes) and added once per block.
+template <int NT, bool DG>       // DG: data-gradient epilogue (residual addend, fused BN-backward sums); else forward (bias, activation, BN statistics)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_gemm10_kernel(GemmArgs a) {
+  constexpr int WC = 8, MT = 2, BNC = 256, BMP = 16 * NT, NTHR = 512;
+  constexpr int RPR = NTHR / 8, XCH = BMP / RPR;             // 64 rows per DMA round; pixel pieces per wave and stage
+  static_assert(BMP % RPR == 0 && NT % 4 == 0 && NT <= 12, "pixel tile");
+  constexpr int STAGE = BMP * ROWB, NSLOT = 6, NSET = 3, DIST = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  long long* tbl_dst = (long long*)(smem + NSLOT * STAGE);   // [2][BMP]
+  uint2* tbl_src = (uint2*)(smem + NSLOT * STAGE + 2 * BMP * 8);   // [2][BMP]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = a.K_pad / BK;
+  const int Kreal = a.ntaps * a.Ci;
+  const unsigned lds0 = lds_addr(smem) + wave * 1024;
+  const int grid = gridDim.x;
+
+  i32x4 srd;
+  {
+    const unsigned long long p = (unsigned long long)a.src;
+    srd[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+    srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    srd[2] = __builtin_amdgcn_readfirstlane((unsigned)((long long)a.N * a.Hs * a.Ws * a.Ci * 2));
+    srd[3] = 0x00020000;
+  }
+  const unsigned OOB = 0xFFFFFFF0u;                           // beyond any tensor the host admits (< 4 GiB): reads as zeros
+  const int rlo = tid >> 3;
+  const int kc = (tid & 7) ^ (rlo & 7);
+  const int fr = lane & 15, fq = lane >> 4;
+  int xro[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) xro[n] = lds_off(n * 16 + fr, fq);
+  const unsigned lane16 = lane * 16;
+
+  auto tile_co0 = [&](int t) { return (xcd_remap(t, a.nblk) % a.tilesC) * BNC; };
+  // row tables of tile t into buffer par (threads < BMP; the caller provides the barrier before anybody reads them)
+  auto make_table = [&](int t, int par) {
+    if (tid < BMP && t < a.nblk) {
+      const int L = xcd_remap(t, a.nblk);
+      const int m = (L / a.tilesC) * BMP + tid;
+      long long off = -1;
+      unsigned xo = 0, vm = 0;
+      if (m < a.M) {
+        int hw = a.Hg * a.Wg;
+        int n = m / hw, rem = m - n * hw;
+        int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+        int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
+        off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
+        int hs = ig * a.in_stride, ws = jg * a.in_stride;
+        xo = (unsigned)(((((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci) * 2);
+        unsigned rsel = 0, csel = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if ((unsigned)(hs + j - 1) < (unsigned)a.Hs) rsel |= (a.rowmask >> (9 * j)) & 0x1FFu;
+          if ((unsigned)(ws + j - 1) < (unsigned)a.Ws) csel |= (a.colmask >> (9 * j)) & 0x1FFu;
+        }
+        vm = rsel & csel;
+      }
+      tbl_dst[par * BMP + tid] = off;
+      tbl_src[par * BMP + tid] = make_uint2(xo, vm);
+    }
+  };
+
+  // ---- issue side: walks (tile, K-step) of this block's tile stream, DIST stages ahead of the multiplies
+  int it_tile = blockIdx.x, it_k = 0, it_par = 0;
+  unsigned xoff[XCH], vmask[XCH];
+  const char* abase = (const char*)a.wpk;
+  int s_tap = 0, s_c0 = 0, s_toff = 0;
+  auto tap_off = [&](int tp_) {
+    const int dh = (int)((a.tapcode >> (4 * tp_)) & 3) - 1;
+    const int dw = (int)((a.tapcode >> (4 * tp_ + 2)) & 3) - 1;
+    return (dh * a.Ws + dw) * a.Ci * 2;
+  };
+  auto enter_tile = [&]() {                                  // it_tile < nblk, its table is in buffer it_par
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const uint2 rs = tbl_src[it_par * BMP + rlo + RPR * i];
+      xoff[i] = rs.x + kc * 16;
+      vmask[i] = rs.y;
+    }
+    const int tc = xcd_remap(it_tile, a.nblk) % a.tilesC;
+    abase = (const char*)a.wpk + ((size_t)(tc * 2 + (wave >> 2)) * nk * 16 + (size_t)(wave & 3) * 4) * 1024;
+    s_tap = 0; s_c0 = 0; s_toff = tap_off(0);
+  };
+  // Past the last tile it issues DUMMY stages - every pixel lane out of range (no memory traffic, zeros into a ring slot
+  // nobody reads again), the last weight fragments once more - so that every K-step is the same straight code.
+  auto issue = [&](int slot, bf16x8 (&f)[2][2]) {
+    const bool real = it_tile < a.nblk;
+    const unsigned bit = 1u << s_tap;
+    const bool kin = real && (it_k * BK + kc * 8 < Kreal);    // K padding of the last step reads as zeros
+    unsigned vo[XCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) vo[i] = ((vmask[i] & bit) && kin && !(a.dbg & 32768)) ? xoff[i] + (unsigned)s_toff : OOB;
+    dma_rows_asm<XCH, RPR * ROWB>(vo, srd, lds0 + slot * STAGE);
+    {
+      // wave-uniform, but carried through the tile switch below: hipcc no longer proves it - pin it to SGPRs
+      const unsigned long long ap = (unsigned long long)(abase + (size_t)((a.dbg & 16384) ? 0 : it_k) * 16384);
+      const unsigned long long au = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ap >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)ap);
+      load_a4_asm(f, lane16, (const void*)au);
+    }
+    if (real) {
+      s_c0 += BK;
+      s_toff += BK * 2;
+      if (s_c0 >= a.Ci) { s_c0 -= a.Ci; ++s_tap; s_toff = tap_off(s_tap) + s_c0 * 2; }
+      if (++it_k == nk) {
+        it_tile += grid;
+        it_par ^= 1;
+        if (it_tile < a.nblk) { it_k = 0; enter_tile(); } else { it_k = nk - 1; }
+      }
+    }
+  };
+
+  // ---- multiply side
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float r1[8], r2[8];                                          // per-channel sums of this lane's 8 channels, over its tiles
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r1[j] = r2[j] = 0.f;
+  const bool stats = !DG && a.stats != nullptr, bnred = DG && a.bn_y != nullptr, addpre = DG && a.addend != nullptr;
+  const int cl8 = wave * 32 + ((fq & 1) << 4) + ((fq >> 1) << 3);   // first of the 8 channels a lane owns after the swap
+
+  auto flush_sums = [&](int co0) {
+    if (!(stats || bnred)) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { r1[j] += __shfl_xor(r1[j], o, 64); r2[j] += __shfl_xor(r2[j], o, 64); }
+    }
+    if (fr == 0 && co0 + cl8 < a.Co) {
+      float* dstp = stats ? a.stats : a.bn_sums;
+      const int rep = blockIdx.x % a.stats_replicas;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(dstp + ((long long)rep * 2 + 0) * a.Co + co0 + cl8 + j, r1[j]);
+        atomicAdd(dstp + ((long long)rep * 2 + 1) * a.Co + co0 + cl8 + j, r2[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r1[j] = r2[j] = 0.f;
+  };
+
+  // accumulators of the finished tile (table buffer par, channel tile co0) -> global memory; clears them
+  auto epilogue = [&](int par, int co0) {
+    const long long* rd = tbl_dst + par * BMP;
+    const int c8 = co0 + cl8;
+    const bool cok = c8 < a.Co;
+    float bs[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = co0 + wave * 32 + m * 16 + fq * 4 + q;
+        bs[m][q] = (!DG && a.bias && c < a.Co) ? a.bias[c] : 0.f;
+      }
+    float bnp[4][8];
+    if (bnred) {
+      const float* ps[4] = {a.bn_scale, a.bn_shift, a.bn_mean, a.bn_invstd};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+        if (cok) { lo = *(const f32x4*)(ps[k] + c8); hi = *(const f32x4*)(ps[k] + c8 + 4); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bnp[k][j] = lo[j]; bnp[k][4 + j] = hi[j]; }
+      }
+    }
+    constexpr int GN = 4;                                      // pixel tiles per pass: bounds the registers of the pass
+#pragma unroll
+    for (int n0 = 0; n0 < NT; n0 += GN) {
+      long long offs[GN];
+#pragma unroll
+      for (int i = 0; i < GN; ++i) offs[i] = rd[(n0 + i) * 16 + fr];
+      uint4 yv4[GN], av4[GN];
+      if (DG) {
+#pragma unroll
+        for (int i = 0; i < GN; ++i) {
+          const bool ok = offs[i] >= 0 && cok;
+          yv4[i] = (bnred && ok) ? *(const uint4*)(a.bn_y + offs[i] + c8) : make_uint4(0, 0, 0, 0);
+          av4[i] = (addpre && ok) ? *(const uint4*)(a.addend + offs[i] + c8) : make_uint4(0, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < GN; ++i) {
+        const int n = n0 + i;
+        unsigned pk[MT][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f32x4 v = acc[m][n];
+          if (!DG) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[q] += bs[m][q];
+              if (a.act_slope != 0.f) v[q] = v[q] > 0.f ? v[q] : v[q] * a.act_slope;
+            }
+          }
+          pk[m][0] = pack2bf(v[0], v[1]);
+          pk[m][1] = pack2bf(v[2], v[3]);
+          acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // even 16-lane rows end with channels 8j .. 8j+7 of the wave's first 16-channel tile, odd rows with those of the second
+        const auto sx = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+        uint4 v = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        const long long off = offs[i];
+        if (off < 0 || !cok) continue;
+        if (addpre) {
+          float f[8], g[8];
+          unpack8(v, f);
+          unpack8(av4[i], g);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] += g[j];
+          v = pack8(f);
+        }
+        if (!(a.dbg & 8192)) *(uint4*)((bf16_t*)a.dst + off + c8) = v;
+        if (stats) {
+          float d[8];
+          unpack8(v, d);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { r1[j] += d[j]; r2[j] = fmaf(d[j], d[j], r2[j]); }
+        } else if (bnred) {
+          float d[8], yv[8];
+          unpack8(v, d);
+          unpack8(yv4[i], yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float z = fmaf(yv[j], bnp[0][j], bnp[1][j]);
+            float dd = z > 0.f ? d[j] : d[j] * a.bn_slope;
+            r1[j] += dd;
+            r2[j] = fmaf(dd * (yv[j] - bnp[2][j]), bnp[3][j], r2[j]);
+          }
+        }
+      }
+    }
+  };
+
+  bf16x8 af[NSET][2][2];
+  // One K-step on ring slot J / register set J % 3 (compile-time):
+  //   [wait: stage s+1 landed] [pre(): deferred work of the tile stream] [read fragments of stage s] [issue stage s+2] |
+  //   [multiply stage s] |        ( | = phase barrier; waves 4-7 are one phase behind waves 0-3)
+  // No branch lies between a load and its wait: pre() may branch, but only touches accumulators, sums and tables.
+  auto step = [&](auto jc, auto&& pre) {
+    constexpr int J = decltype(jc)::value;
+    constexpr int S = J % NSET, S1 = (J + 1) % NSET, S2 = (J + DIST) % NSET, J2 = (J + DIST) % NSLOT;
+    wait_a4<0>(af[S1]);
+    pre();
+    const unsigned char* sb = smem + J * STAGE;
+    // pixel fragments in groups of NH tiles: all eight of a 128-pixel tile; halves of a 192-pixel tile (12 + 12 fragments
+    // beside 96 accumulators and three weight sets would spill).  Group (0, 0) is read in the memory phase.
+    constexpr int NH = NT > 8 ? NT / 2 : NT;
+    bf16x8 xf[NH];
+#pragma unroll
+    for (int n = 0; n < NH; ++n) xf[n] = *(const bf16x8*)(sb + xro[n]);
+    issue(J2, af[S2]);
+    phase_barrier();
+#pragma unroll
+    for (int h = 0; h < NT / NH; ++h)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if (h + kk) {
+#pragma unroll
+          for (int n = 0; n < NH; ++n) xf[n] = *(const bf16x8*)(sb + (xro[h * NH + n] ^ (kk << 6)));
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NH; ++n)
+            acc[m][h * NH + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[S][m][kk], xf[n], acc[m][h * NH + n], 0, 0, 0);
+      }
+    phase_barrier();
+  };
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
+  using J2_ = std::integral_constant<int, 2>;
+  using J3 = std::integral_constant<int, 3>;
+  using J4 = std::integral_constant<int, 4>;
+  using J5 = std::integral_constant<int, 5>;
+
+  // ---- start of the stream
+  make_table(blockIdx.x, 0);
+  lds_barrier();
+  enter_tile();
+  issue(0, af[0]);
+  issue(1, af[1]);
+  wait_a4<0>(af[0]);
+  phase_barrier();
+  if (wave >= WC / 2) phase_barrier();                         // waves 4-7: one phase behind
+  const int ngroups = nk / NSLOT;
+  bool pending = false;
+  int pend_par = 0, pend_co0 = 0, par = 0;
+  for (int t = blockIdx.x; t < a.nblk; t += grid) {
+    const int co0 = tile_co0(t);
+    for (int g = 0; g < ngroups; ++g) {
+      step(J0{}, [&] {
+        if (g == 0 && pending) {                               // the previous tile's accumulators leave right behind this wait
+          epilogue(pend_par, pend_co0);
+          if (pend_co0 != co0) flush_sums(pend_co0);
+          pending = false;
+        }
+      });
+      step(J1{}, [&] {
+        if (g == 0) make_table(t + grid, par ^ 1);             // its readers are at least one barrier away; the buffer was
+      });                                                      // last read by the epilogue in the step before
+      step(J2_{}, [] {});
+      step(J3{}, [] {});
+      step(J4{}, [] {});
+      step(J5{}, [] {});
+    }
+    pending = true; pend_par = par; pend_co0 = co0;
+    par ^= 1;
+  }
+  if (wave < WC / 2) phase_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_nop 7" ::: "memory");
+  if (pending) {
+    epilogue(pend_par, pend_co0);
+    flush_sums(pend_co0);
+  }
+}
+
+template <int NT, bool DG>
+int launch_gemm10(GemmArgs& a, hipStream_t st) {
+  constexpr int BMP = 16 * NT;
+  a.tilesC = a.Co_pad / 256;
+  a.nblk = a.tilesC * cdiv(a.M, BMP);
+  size_t lds = (size_t)6 * BMP * ROWB + (size_t)2 * BMP * 16 + 64;
+  auto k = conv_gemm10_kernel<NT, DG>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  int grid = a.nblk < 256 ? a.nblk : 256;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2947,6 +3339,33 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
       return MGD_OK;
     }
     {
+      // streaming ping-pong form (conv_gemm10_kernel): 256-channel blocks, K-loops of whole groups of 6 steps
+      static int g10 = -1;
+      if (g10 < 0) { const char* e = getenv("MGD_GEMM10"); g10 = e ? atoi(e) : 0; }
+      if (g10 && !d->dst_f32 && !((d->addend || d->bn_y) && (d->bias || d->stats || d->act_slope != 0.f)) && d->Co_pad % 256 == 0 && d->ntaps > 1 && d->Ci % 64 == 0 && nk % 6 == 0 && nk >= 6) {
+        a.rowmask = a.colmask = 0;
+        for (int t = 0; t < d->ntaps; ++t) {
+          a.rowmask |= 1u << (9 * (d->dh[t] + 1) + t);
+          a.colmask |= 1u << (9 * (d->dw[t] + 1) + t);
+        }
+        // pixel tile: 192 pixels balance the memory phase of one wave group against the multiply phase of the other (7
+        // vector-memory instructions per 48 MFMA instead of 6 per 32); 128 where 192 quantises worse on the 256 CUs
+        static int g10nt = -1;
+        if (g10nt < 0) { const char* e = getenv("MGD_GEMM10_NT"); g10nt = e ? atoi(e) : 0; }
+        int nt = g10nt;
+        if (nt != 8 && nt != 12) {
+          const long long t12 = (long long)(d->Co_pad / 256) * cdiv(a.M, 192), t8 = (long long)(d->Co_pad / 256) * cdiv(a.M, 128);
+          const double c12 = (double)((t12 + 255) / 256) * 12 * 0.92, c8 = (double)((t8 + 255) / 256) * 8;
+          nt = c12 <= c8 ? 12 : 8;
+        }
+        const bool dg = d->addend || d->bn_y;
+        if (nt == 12) { if (dg) launch_gemm10<12, true>(a, st); else launch_gemm10<12, false>(a, st); }
+        else { if (dg) launch_gemm10<8, true>(a, st); else launch_gemm10<8, false>(a, st); }
+        MGD_CHECK_LAUNCH("conv_gather_gemm(streaming ping-pong)");
+        return MGD_OK;
+      }
+    }
+    {
       // hand-counted pipeline (conv_gemm9_kernel): bf16 output, wave-uniform (tap, channel) per K-step
       static int g9 = -1, g9nt = -1, g9wc = -1, g9grid = -1, g9cnt = -1, g9one = -1;
       if (g9 < 0) {
@@ -3004,10 +3423,9 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
         static int g9pp = -1;
         if (g9pp < 0) { const char* e = getenv("MGD_GEMM9_PP"); g9pp = e ? atoi(e) : 0; }
         if (g9pp && wc == 8 && (nt == 8 || nt == 12) && nk >= 3) {
-          // ping-pong form: g9pp = ring slots (3: one stage in flight, 4: two); default the one that pads the K-loop less
-          int nb = g9pp == 3 || g9pp == 4 ? g9pp : ((nk % 4 == 0 || (nk % 3 && nk % 4 >= nk % 3)) ? 4 : 3);
-          if (nt == 8) { if (nb == 4) launch_gemm9<8, 8, 4, true>(a, st, cap); else launch_gemm9<8, 8, 3, true>(a, st, cap); }
-          else { if (nb == 4) launch_gemm9<8, 12, 4, true>(a, st, cap); else launch_gemm9<8, 12, 3, true>(a, st, cap); }
+          if (nt == 8 && (a.dbg & 4096)) launch_gemm9<8, 8, 4, true, true>(a, st, cap);      // stamped diagnostic build
+          else if (nt == 8) launch_gemm9<8, 8, 4, true>(a, st, cap);
+          else launch_gemm9<8, 12, 4, true>(a, st, cap);
           MGD_CHECK_LAUNCH("conv_gather_gemm(counted pipeline, ping-pong)");
           return MGD_OK;
         }
@@ -3244,3 +3662,11 @@ extern "C" int mgd_pack_weights_batch(const mgd_pack_job* jobs_dev, int njobs, i
   return MGD_OK;
 }
 
+// Diagnostic: reads and clears the phase stamps of the stamped conv_gemm9_kernel build (MGD_DBG=4096, MGD_GEMM9_PP=4).
+extern "C" int mgd_debug_stamps(unsigned long long* out16) {
+  MGD_REQUIRE(out16, "debug_stamps: null pointer");
+  unsigned long long z[24] = {0};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(z)) != hipSuccess) return MGD_EINVAL;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return MGD_EINVAL;
+  return MGD_OK;
+}
