@@ -2337,6 +2337,223 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradient v4 (round 3): conv_wgrad2_kernel with the address arithmetic taken out of the vector ALU.
+// PMC counters of v2 on 128 -> 256 at 76 x 76 (tools/prof_conv.sh): 9 VALU instructions per MFMA - 125 per K-step and wave
+// carrying (row, column, image) of the staged pixels, testing tap bounds and selecting 64-bit source addresses - the SIMDs'
+// vector issue 60 % busy, the matrix pipe 24 %.  For stride-1 'same' convolutions none of it is needed:
+//  * the staged rows of a K-step are 64 CONSECUTIVE pixels, and both operands are linear in the flat pixel index (the
+//    input shifted by the tap: pixel p + dh*W + dw) - so each lane's byte offset is a CONSTANT, and the K-step advance moves
+//    the base of a raw buffer descriptor held in SGPRs (three scalar instructions per operand and step);
+//  * the end of the block's pixel range is the descriptor's num_records: rows past it read as zeros in hardware;
+//  * the only per-pixel fact left, "does this tap stay inside the image at pixel q", is one bit: the block builds the bit
+//    map of ITS tap over one image (H*W bits, <= 23 words at 76 x 76... 181 words) in LDS once, and a staged input row costs an
+//    index update, an LDS word, a bit test and a select per K-step.
+// Same tiles, ring, transposed fragment reads and atomic epilogue as v2.
+template <int WC, int WI, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
+  constexpr int BCO = WC * MT * 16;
+  constexpr int BCI = WI * NT * 16;
+  static_assert(WC * WI == 4, "4 waves");
+  constexpr int RBO = BCO * 2, RBI = BCI * 2;
+  constexpr int OCH = RBO / 64, ICH = RBI / 64;        // LDS-DMA instructions per wave per stage
+  constexpr int ORPI = 1024 / RBO, IRPI = 1024 / RBI;  // rows per wave-instruction
+  constexpr int STAGE = 64 * (RBO + RBI);
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* mbits = (unsigned*)(smem + 2 * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave / WI, wi = wave % WI;
+
+  int b = blockIdx.x;
+  const int tco = b % a.tilesCo; b /= a.tilesCo;
+  const int tci = b % a.tilesCi; b /= a.tilesCi;
+  const int tap = b % a.ntaps;
+  const int split = b / a.ntaps;
+  const int co0 = tco * BCO, ci0 = tci * BCI;
+  const int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
+  const int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
+  const int pbeg = split * a.chunk;
+  const int pend = min(a.P, pbeg + a.chunk);
+  const int nk = (pend - pbeg + 63) / 64;
+  const int HW = a.Hg * a.Wg;
+  const unsigned OOB = 0xFFFFFFF0u;
+
+  // bit q of the map: the tap's source pixel of output pixel q (of one image) lies inside the image
+  const bool masked = dh != 0 || dw != 0;
+  if (masked) {
+    for (int w = tid; w < (HW + 31) / 32; w += 256) {
+      const int q0 = w * 32;
+      int i = q0 / a.Wg, j = q0 - i * a.Wg;
+      unsigned bits = 0;
+      for (int t = 0; t < 32; ++t) {
+        const bool ok = q0 + t < HW && (unsigned)(i + dh) < (unsigned)a.Hg && (unsigned)(j + dw) < (unsigned)a.Wg;
+        bits |= (ok ? 1u : 0u) << t;
+        if (++j == a.Wg) { j = 0; ++i; }
+      }
+      mbits[w] = bits;
+    }
+  }
+
+  // raw buffer descriptors over the block's pixel range; the K-loop moves base and num_records by one 64-pixel step
+  const long long dstep = (long long)a.Co * 128, xstep = (long long)a.Ci * 128;
+  unsigned long long obase = (unsigned long long)a.dy + (unsigned long long)((long long)pbeg * a.Co * 2);
+  // (the input base may lie before the tensor for the upper taps of the first pixels: those rows are masked, never fetched)
+  unsigned long long xbase = (unsigned long long)((long long)(unsigned long long)a.src + ((long long)pbeg + (long long)dh * a.Ws + dw) * a.Ci * 2);
+  long long orec = (long long)(pend - pbeg) * a.Co * 2, xrec = (long long)(pend - pbeg) * a.Ci * 2;
+  auto make_srd = [&](unsigned long long base, long long rec) {
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((base >> 32) & 0xFFFFu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)(unsigned)(rec > 0 ? rec : 0));
+    r[3] = 0x00020000;
+    return r;
+  };
+
+  // per-thread constant byte offsets (row in the 64-pixel step, logical chunk) for both tiles
+  const int o_rl = lane / (RBO / 16), o_s = lane % (RBO / 16);
+  const int i_rl = lane / (RBI / 16), i_s = lane % (RBI / 16);
+  unsigned o_off[OCH], x_off[ICH];
+  int x_q[ICH];                                        // the staged input row's pixel index inside its image
+#pragma unroll
+  for (int i = 0; i < OCH; ++i) {
+    const int r = (i * 4 + wave) * ORPI + o_rl;
+    const int ch = (((o_s >> 1) ^ tr_swz(r, RBO / 32)) << 1) | (o_s & 1);
+    const int c = co0 + ch * 8;
+    o_off[i] = c < a.Co ? (unsigned)((r * a.Co + c) * 2) : OOB;
+  }
+  const int adv = 64 % HW;
+#pragma unroll
+  for (int i = 0; i < ICH; ++i) {
+    const int r = (i * 4 + wave) * IRPI + i_rl;
+    const int ch = (((i_s >> 1) ^ tr_swz(r, RBI / 32)) << 1) | (i_s & 1);
+    const int c = ci0 + ch * 8;
+    x_off[i] = c < a.Ci ? (unsigned)((r * a.Ci + c) * 2) : OOB;
+    x_q[i] = (pbeg + r) % HW;
+  }
+  __syncthreads();                                     // bit map published
+
+  // prep(): the input rows' offsets of the NEXT stage to issue (bit test against the map), behind the first MFMAs of the
+  // previous step; fire(): the six LDS-DMA instructions, right after the barrier, then the descriptors move on
+  unsigned xv[ICH];
+  auto prep = [&]() {
+#pragma unroll
+    for (int i = 0; i < ICH; ++i) {
+      unsigned ok = 1u;
+      if (masked) ok = (mbits[x_q[i] >> 5] >> (x_q[i] & 31)) & 1u;
+      xv[i] = ok ? x_off[i] : OOB;
+      x_q[i] += adv;
+      x_q[i] -= x_q[i] >= HW ? HW : 0;
+    }
+  };
+  const unsigned smem_a = lds_addr(smem);
+  auto fire = [&](int buf) {
+    const unsigned ob = smem_a + buf * STAGE + wave * 1024;
+    dma_rows_asm<OCH, 4096>(o_off, make_srd(obase, orec), ob);
+    dma_rows_asm<ICH, 4096>(xv, make_srd(xbase, xrec), ob + 64 * RBO);
+    obase += dstep; orec -= dstep;
+    xbase += xstep; xrec -= xstep;
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  prep();
+  if (nk > 0) fire(0);
+  prep();                   // offsets of step 1
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  int o_rd[2][2][MT], i_rd[2][2][NT];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r0 = kk * 32 + 8 * g + qq + 4 * h;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) o_rd[kk][h][m] = r0 * RBO + (((wc * MT + m) ^ tr_swz(r0, RBO / 32)) * 32) + pp * 8;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        i_rd[kk][h][n] = 64 * RBO + r0 * RBI + (((wi * NT + n) ^ tr_swz(r0, RBI / 32)) * 32) + pp * 8;
+    }
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  // fragment read addresses are per-lane constants; the ring slot is an immediate offset (the loop is unrolled by two)
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) o_rd[kk][h][m] += smem_a;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) i_rd[kk][h][n] += smem_a;
+    }
+  auto kstep = [&](auto bc, int ks) {
+    constexpr int BUF = decltype(bc)::value;
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    const bool more = ks + 1 < nk;
+    s16x4 fa[2][MT][2], fb[2][NT][2];
+    auto read_half = [&](int kk) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        tr_read_asm<BUF * STAGE>(fa[kk][m][0], (unsigned)o_rd[kk][0][m]);
+        tr_read_asm<BUF * STAGE>(fa[kk][m][1], (unsigned)o_rd[kk][1][m]);
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        tr_read_asm<BUF * STAGE>(fb[kk][n][0], (unsigned)i_rd[kk][0][n]);
+        tr_read_asm<BUF * STAGE>(fb[kk][n][1], (unsigned)i_rd[kk][1][n]);
+      }
+    };
+    auto mfma_half = [&](int kk) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { touch(fa[kk][m][0]); touch(fa[kk][m][1]); }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { touch(fb[kk][n][0]); touch(fb[kk][n][1]); }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        s16x8 av = __builtin_shufflevector(fa[kk][m][0], fa[kk][m][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          s16x8 bv = __builtin_shufflevector(fb[kk][n][0], fb[kk][n][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                             acc[m][n], 0, 0, 0);
+        }
+      }
+    };
+    if (more) fire(BUF ^ 1);
+    read_half(0);
+    wait_lgkm_dyn(0);
+    read_half(1);          // in flight under the MFMAs of the first half
+    mfma_half(0);
+    prep();                // offsets of step ks + 2 (its LDS word is back long before the next fire)
+    wait_lgkm_dyn(0);
+    mfma_half(1);
+  };
+  for (int ks = 0; ks < nk; ks += 2) {
+    kstep(std::integral_constant<int, 0>{}, ks);
+    if (ks + 1 < nk) kstep(std::integral_constant<int, 1>{}, ks + 1);
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  if (a.dbg & 32) return;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + (wc * MT + m) * 16 + fq * 4 + r;
+      if (co >= a.Co) continue;
+      float* row = a.dw + ((long long)co * a.ntaps + tap) * a.Ci;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int ci = ci0 + (wi * NT + n) * 16 + fr;
+        if (ci >= a.Ci) continue;
+        if (a.dbg & 16) row[ci] = acc[m][n][r]; else atomicAdd(row + ci, acc[m][n][r]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient v3 ("patch" form) for 3x3 convs with few input channels (Ci = 32 or 64), stride 1 or 2.
 // With so few channels the per-tap blocks of v2 move 3x more LDS-DMA bytes per FLOP than a 128x128 tile and
 // re-read dy nine times.  Here one block owns ALL nine taps of a [64 co] x [Ci] slice: per K-step (an
@@ -3209,6 +3426,23 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   return 0;
 }
 
+template <int WC, int WI, int MT, int NT>
+int launch_wgrad4(WgradArgs& a, hipStream_t st) {
+  constexpr int BCO = WC * MT * 16, BCI = WI * NT * 16;
+  a.tilesCo = cdiv(a.Co, BCO);
+  a.tilesCi = cdiv(a.Ci, BCI);
+  size_t lds = (size_t)64 * (BCO + BCI) * 2 * 2 + (size_t)((a.Hg * a.Wg + 31) / 32) * 4 + 16;   // ring + the tap's bit map
+  auto k = conv_wgrad4_kernel<WC, WI, MT, NT>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    attr = true;
+  }
+  int nblk = a.tilesCo * a.tilesCi * a.ntaps * a.splits;
+  hipLaunchKernelGGL(k, dim3(nblk), dim3(256), lds, st, a);
+  return 0;
+}
+
 template <int MT, int NT, int PPW>
 int launch_wgrad3(Wgrad3Args& a, hipStream_t st) {
   constexpr int BCO = 2 * MT * 16;
@@ -3328,16 +3562,6 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   //    (1024->512 at 19x19, 184 tiles: 66 us against 108);
   //  * everything else: weights straight from global memory, three blocks per CU.
   if (d->Co_pad % 128 == 0) {
-    static int pc = -1;
-    if (pc < 0) { const char* e = getenv("MGD_PRODCONS"); pc = e ? atoi(e) : 1; }
-    const long long nblk128 = (long long)(d->Co_pad / 128) * cdiv(a.M, 128);
-    if (nk >= 4 && !d->dst_f32 && (variant == 9 || (pc && nblk128 <= 256))) {
-      static int ns6 = -1;
-      if (ns6 < 0) { const char* e = getenv("MGD_PC_STAGES"); ns6 = e ? atoi(e) : 4; }   // 4 stages: equal to 3 alone, 0.2 % faster inside the step (latency under the side stream)
-      if (ns6 == 4) launch_gemm6<2, 2, 4, 4, 4>(a, st); else launch_gemm6<2, 2, 4, 4, 3>(a, st);
-      MGD_CHECK_LAUNCH("conv_gather_gemm(producer/consumer)");
-      return MGD_OK;
-    }
     {
       // streaming ping-pong form (conv_gemm10_kernel): 256-channel blocks, K-loops of whole groups of 6 steps
       static int g10 = -1;
@@ -3369,14 +3593,27 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
       // hand-counted pipeline (conv_gemm9_kernel): bf16 output, wave-uniform (tap, channel) per K-step
       static int g9 = -1, g9nt = -1, g9wc = -1, g9grid = -1, g9cnt = -1, g9one = -1;
       if (g9 < 0) {
-        const char* e = getenv("MGD_GEMM9"); g9 = e ? atoi(e) : 0;
+        const char* e = getenv("MGD_GEMM9"); g9 = e ? atoi(e) : -1;   // -1: where it measured faster (below); 0: never; 1..4: wherever it applies
         e = getenv("MGD_GEMM9_NT"); g9nt = e ? atoi(e) : 0;
         e = getenv("MGD_GEMM9_WC"); g9wc = e ? atoi(e) : 0;
         e = getenv("MGD_GEMM9_GRID"); g9grid = e ? atoi(e) : -1;      // -1: one block per slot (persistent); 0: one block per tile
         e = getenv("MGD_GEMM9_CNT"); g9cnt = e ? atoi(e) : 1;
         e = getenv("MGD_GEMM9_1X1"); g9one = e ? atoi(e) : 0;         // 1: also the 1x1 convolutions
       }
-      if (g9 && !d->dst_f32 && ((d->ntaps == 1 && g9one) || (d->ntaps > 1 && d->Ci % 64 == 0)) && nk >= 2) {
+      // Default (g9 = -1), from tools/bench_conv.py at 608 x 608, batch 16, each launch alone:
+      //  * long K-loops on 256-channel blocks (nk >= 64, or nk >= 36 with at most 512 tiles of 128 x 128): ping-pong form -
+      //    512 -> 1024 at 19 x 19 64 -> 56 us, its stride-2 entry 66 -> 57 us, the data gradient of 256 -> 512 at 38 x 38 65 -> 55 us;
+      //  * launches of at most 512 tiles with short K-loops (the head's 3x3 convolutions): 4-wave form, three stages -
+      //    128 -> 256 at 38 x 38 25.7 -> 21.9 us, 128 -> 352 33.6 -> 30.9 us, 256 -> 704 at 19 x 19 35.7 -> 31.1 us;
+      //  * everything else stays on conv_gemm8_kernel (three blocks per CU): 128 -> 256 at 76 x 76 and 256 -> 512 at 38 x 38
+      //    forward measured 66 / 59 us there against 67 - 76 / 59 - 69 us for every tile shape of the new forms.
+      bool use9 = g9 > 0, force_pp = false;
+      if (g9 < 0 && !d->dst_f32 && d->ntaps > 1 && d->Ci % 64 == 0 && nk >= 4) {
+        const long long tiles128 = (long long)(d->Co_pad / 128) * cdiv(a.M, 128);
+        if (d->Co_pad % 256 == 0 && (nk >= 64 || (nk >= 36 && tiles128 <= 512))) { use9 = true; force_pp = true; }
+        else if (tiles128 <= 512 && nk <= 36) use9 = true;
+      }
+      if (use9 && !d->dst_f32 && ((d->ntaps == 1 && g9one) || (d->ntaps > 1 && d->Ci % 64 == 0)) && nk >= 2) {
         // Tile shape.  The K-loop is bound by the CU's vector-memory path (~25 B/clk delivered, weights + pixels), so the
         // cost of a launch is modelled as rounds x K-steps x bytes per step of the resident blocks of a CU; wider tiles move
         // fewer bytes per FLOP but quantise worse on 256 CUs.  8 waves x 256 channels: one block per CU; 4 waves x 128
@@ -3388,6 +3625,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
           for (int c = 0; c < 7; ++c) {
             if (g9wc && cw[c] != g9wc) continue;
             if (g9nt && cn[c] != g9nt) continue;
+            if (g9 < 0 && (force_pp ? !(cw[c] == 8 && cn[c] == 8) : cw[c] != 4)) continue;
             if (cw[c] == 8 && d->Co_pad % 256) continue;
             const int slots = cw[c] == 8 ? 256 : 512, per_cu = cw[c] == 8 ? 1 : 2;
             const long long tiles = (long long)(d->Co_pad / (32 * cw[c])) * cdiv(a.M, cn[c] * 16);
@@ -3422,7 +3660,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
         (void)g9cnt;
         static int g9pp = -1;
         if (g9pp < 0) { const char* e = getenv("MGD_GEMM9_PP"); g9pp = e ? atoi(e) : 0; }
-        if (g9pp && wc == 8 && (nt == 8 || nt == 12) && nk >= 3) {
+        if ((g9pp || force_pp) && wc == 8 && (nt == 8 || nt == 12) && nk >= 3) {
           if (nt == 8 && (a.dbg & 4096)) launch_gemm9<8, 8, 4, true, true>(a, st, cap);      // stamped diagnostic build
           else if (nt == 8) launch_gemm9<8, 8, 4, true>(a, st, cap);
           else launch_gemm9<8, 12, 4, true>(a, st, cap);
@@ -3435,6 +3673,16 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
         MGD_CHECK_LAUNCH("conv_gather_gemm(counted pipeline)");
         return MGD_OK;
       }
+    }
+    static int pc = -1;
+    if (pc < 0) { const char* e = getenv("MGD_PRODCONS"); pc = e ? atoi(e) : 1; }
+    const long long nblk128 = (long long)(d->Co_pad / 128) * cdiv(a.M, 128);
+    if (nk >= 4 && !d->dst_f32 && (variant == 9 || (pc && nblk128 <= 256))) {
+      static int ns6 = -1;
+      if (ns6 < 0) { const char* e = getenv("MGD_PC_STAGES"); ns6 = e ? atoi(e) : 4; }   // 4 stages: equal to 3 alone, 0.2 % faster inside the step (latency under the side stream)
+      if (ns6 == 4) launch_gemm6<2, 2, 4, 4, 4>(a, st); else launch_gemm6<2, 2, 4, 4, 3>(a, st);
+      MGD_CHECK_LAUNCH("conv_gather_gemm(producer/consumer)");
+      return MGD_OK;
     }
     static int g8wc = -1;
     // four waves along the channels (32 x 128 wave tiles): every weight fragment is loaded by exactly one wave - with 2 x 2
@@ -3572,7 +3820,15 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
   // 128 x 64 tiles: 48 KB of LDS, so three blocks share a CU - 8 % faster over the graph than 128 x 128 with two, although
   // a block stages half as many MACs per LDS-DMA byte (three waves per SIMD hide the ring's round trips better)
   if (wtile < 0) { const char* e = getenv("MGD_WGRAD_TILE"); wtile = e ? atoi(e) : 1; }
-  if (co > 64 && ci > 64 && wtile == 1) launch_wgrad<2, 2, 4, 2>(a, st);
+  // stride-1 'same' geometry (every 1x1, every stride-1 3x3): descriptor-addressed form, no per-pixel address arithmetic
+  static int w4 = -1;
+  if (w4 < 0) { const char* e = getenv("MGD_WGRAD4"); w4 = e ? atoi(e) : 1; }
+  const bool lin = d->in_stride == 1 && d->Hs == d->Hg && d->Ws == d->Wg &&
+                   (long long)a.chunk * (co > ci ? co : ci) * 2 < (1ll << 31) && d->Hg * d->Wg <= 64 * 1024;
+  if (w4 && lin && co > 64 && ci > 64 && wtile == 0) launch_wgrad4<2, 2, 4, 4>(a, st);
+  else if (w4 && lin && co > 64 && ci > 64 && wtile == 1) launch_wgrad4<2, 2, 4, 2>(a, st);
+  else if (w4 && lin && co > 32 && ci > 32 && !(co > 64 && ci > 64)) launch_wgrad4<2, 2, 2, 2>(a, st);
+  else if (co > 64 && ci > 64 && wtile == 1) launch_wgrad<2, 2, 4, 2>(a, st);
   else if (co > 64 && ci > 64 && wtile == 2) launch_wgrad<2, 2, 2, 4>(a, st);   // 64 x 128 (slower)
   else if (co > 64 && ci > 64) launch_wgrad<2, 2, 4, 4>(a, st);
   else if (co > 32 && ci > 32) launch_wgrad<2, 2, 2, 2>(a, st);
