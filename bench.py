@@ -7,10 +7,12 @@ batch 16 per GPU, on N MI355X of one node (BASELINE.json `metric`; SURVEY.md §8
          bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  Inputs (synthetic COCO-shaped images + boxes) are resident in HBM before
-the timed region.  `roofline` is for the dominant kernel - whichever of the three 128x128-tile bf16 MFMA
-convolution kernels (weight gradient, producer/consumer gather-GEMM, barrier-synchronous gather-GEMM) takes the
-largest share of the step: algorithmic conv FLOPs of its launches / their summed durations, measured with HIP
-events on the launch stream inside the timed region; the other two are listed under `other_kernels`.
+the timed region.  `roofline` is for the dominant kernel - whichever of the large-tile bf16 MFMA convolution kernel
+families (the library reports the family of every launch: mgd_last_kernel) takes the largest share of the step: algorithmic
+conv FLOPs of its launches / their summed durations, measured with HIP events on the launch stream inside the timed region;
+the others are listed under `other_kernels`.  `roofline.per_layer`: every distinct 3x3 convolution of the backbone at the
+benchmark shape, forward / data gradient / weight gradient each launched alone (north_star's per-layer MFMA figure, from
+this run).  `infer`: forward + decode + DIoU-NMS at batch 16 and 1, each with its own MFMA roofline.
 `cpu_baseline` times the oracle (torch-CPU restatement of the same train step) on the host cores, rank 0,
 N=1 only, on a bounded sample.
 """
@@ -129,20 +131,67 @@ def infer_bench(dev, size, steps=20, warmup=3):
                 e2.record()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            fwd_ms = e0.elapsed_time(e1)
+            ach = batch * FLOP_PER_IMAGE_FWD * (size / 608) ** 2 / (fwd_ms * 1e-3) / 1e12
             runs.append({"batch": batch, "fold_bn": fold, "images_per_sec": round(batch * steps / dt, 1),
-                         "ms_per_batch": round(1e3 * dt / steps, 3), "forward_ms": round(e0.elapsed_time(e1), 3),
-                         "decode_nms_ms": round(e1.elapsed_time(e2), 3), "detections_last_batch": int(r[3].sum())})
+                         "ms_per_batch": round(1e3 * dt / steps, 3), "forward_ms": round(fwd_ms, 3),
+                         "decode_nms_ms": round(e1.elapsed_time(e2), 3), "detections_last_batch": int(r[3].sum()),
+                         "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                                      "note": "conv FLOPs of the forward pass (112.11 GFLOP per 608x608 image) / its HIP-event time, last batch"}})
     model.fold_bn(False)
     return {"metric": "inference images/sec incl. decode + DIoU-NMS", "size": size, "steps": steps, "warmup": warmup,
             "nms": "diou", "confidence": 0.008, "max_boxes": 100, "dtype": "bf16",
             "data": "synthetic, random-init weights, moving BN statistics", "runs": runs}
 
 
+def per_layer_bench(dev, size, batch, iters=5):
+    """north_star's "fraction of the conv-MFMA roofline on backbone 3x3 convs", from the driver's own run: every distinct
+    3x3 convolution of the backbone at the benchmark shape, forward / data gradient / weight gradient each launched ALONE
+    (HIP events around `iters` launches, one warm-up), as TFLOP/s and as a fraction of the dense bf16 peak."""
+    from multigriddet_amd import ops
+    rows = []
+    h = size
+    for f in (64, 128, 256, 512, 1024):
+        for (ci, co, s, hin, count) in ((f // 2, f, 2, h, 1), (f // 2, f, 1, h // 2, {64: 1, 128: 2, 256: 8, 512: 8, 1024: 4}[f])):
+            ho = hin // s
+            x = torch.randn(batch, hin, hin, ci, device=dev).to(torch.bfloat16)
+            dy = torch.randn(batch, ho, ho, co, device=dev).to(torch.bfloat16)
+            w = torch.randn(co, 9, ci, device=dev) * 0.05
+            pk = ops.PackedConv(co, ci, 3, s, dev)
+            pk.refresh(w)
+            y = torch.empty(batch, ho, ho, co, dtype=torch.bfloat16, device=dev)
+            dx = torch.empty(batch, hin, hin, ci, dtype=torch.bfloat16, device=dev)
+            dw = torch.zeros(co, 9, ci, device=dev)
+            st = torch.zeros(ops.STATS_REPLICAS, 2, co, device=dev)
+            fl = 2.0 * batch * ho * ho * 9 * ci * co
+
+            def t(fn):
+                fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e-3 / iters
+            tf = [fl / t(fn) / 1e12 for fn in (lambda: ops.conv_fwd(x, pk, out=y, stats=st),
+                                               lambda: ops.conv_dgrad(dy, pk, (hin, hin), out=dx),
+                                               lambda: ops.conv_wgrad(x, dy, dw, 3, s))]
+            rows.append({"layer": f"{ci}->{co} 3x3 s{s} @{hin}", "count": count, "gflop": round(fl / 1e9, 2),
+                         "fwd_tflops": round(tf[0], 1), "dgrad_tflops": round(tf[1], 1), "wgrad_tflops": round(tf[2], 1),
+                         "fwd_frac": round(tf[0] / PEAK_BF16_TFLOPS, 3), "dgrad_frac": round(tf[1] / PEAK_BF16_TFLOPS, 3),
+                         "wgrad_frac": round(tf[2] / PEAK_BF16_TFLOPS, 3)})
+        h //= 2
+    return rows
+
+
 def pmc_traffic(prefix="conv_wgrad2_kernel<2, 2, 4, 2>"):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (collected in separate
     rocprofv3 --pmc passes of this same command; FETCH_SIZE x2 on gfx950 + WRITE_SIZE); (None, reason) if absent."""
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r02_pmc_traffic.txt", "r01_pmc_traffic.txt"):          # newest committed summary first
+    for name in ("r03_pmc_traffic.txt", "r02_pmc_traffic.txt", "r01_pmc_traffic.txt"):          # newest committed summary first
         try:
             for line in open(os.path.join(root, name)):
                 if line.startswith(prefix):
@@ -233,12 +282,18 @@ def main():
     ips = world * args.batch * args.steps / dt
     roof = None
     if prof:
-        names = {"gemm128": "conv_gemm8_kernel<2,3> (128x128-tile bf16 MFMA gather-GEMM, weight fragments from global memory, "
-                            "pixel tile through an LDS-DMA ring, three blocks per CU: 3x3/1x1 conv forward + data gradient)",
-                 "gemm128pc": "conv_gemm6_kernel<2,2,4,4,4> (128x128-tile bf16 MFMA gather-GEMM, producer/consumer waves)",
-                 "wgrad128": "conv_wgrad2_kernel<2,2,4,2> (128x64-tile bf16 MFMA weight gradient, per-tap blocks, split-K, three blocks per CU)"}
-        pmc_keys = {"gemm128": "conv_gemm8_kernel<2, 3,", "gemm128pc": "conv_gemm6_kernel<2, 2, 4, 4",
-                    "wgrad128": "conv_wgrad2_kernel<2, 2, 4, 2>"}
+        # kernel families as the library names them (mgd_last_kernel): description + the kernel-name prefix of the PMC summary
+        fam = {
+            "conv_gather_gemm(global weight fragments)": ("conv_gemm8_kernel<2,3> (128x128-tile bf16 MFMA gather-GEMM, weight fragments from "
+                                                          "global memory, pixel tile through an LDS-DMA ring, three blocks per CU)", "conv_gemm8_kernel<2, 3,"),
+            "conv_gather_gemm(producer/consumer)": ("conv_gemm6_kernel<2,2,4,4,4> (128x128-tile gather-GEMM, producer/consumer waves)", "conv_gemm6_kernel<2, 2, 4, 4"),
+            "conv_gather_gemm(counted pipeline)": ("conv_gemm9_kernel<4,NT,NST> (gather-GEMM, hand-counted asm memory pipeline, two blocks per CU)", "conv_gemm9_kernel<4,"),
+            "conv_gather_gemm(counted pipeline, ping-pong)": ("conv_gemm9_kernel<8,8,4,true> (256x128-tile gather-GEMM, 8 waves in ping-pong phases)", "conv_gemm9_kernel<8,"),
+            "conv_gather_gemm(streaming ping-pong)": ("conv_gemm10_kernel (256-channel streaming ping-pong gather-GEMM)", "conv_gemm10_kernel"),
+            "conv_wgrad(descriptor-addressed)": ("conv_wgrad4_kernel<2,2,4,2> (128x64-tile bf16 MFMA weight gradient, per-tap blocks, split-K, "
+                                                 "descriptor-addressed operands, three blocks per CU)", "conv_wgrad4_kernel<2, 2, 4, 2>"),
+            "conv_wgrad": ("conv_wgrad2_kernel (per-tap weight gradient, carried addresses: stride-2 layers)", "conv_wgrad2_kernel<2, 2, 4, 2>"),
+        }
         step_ms = dt * 1e3 / args.steps
 
         def summarise(tag, only=None):
@@ -250,20 +305,24 @@ def main():
             return {"achieved": round(ach, 2), "frac": round(ach / PEAK_BF16_TFLOPS, 4), "launches": n,
                     "avg_launch_us": round(1e3 * ms / max(n, 1), 2), "share_of_step_time": round(ms / step_ms, 3),
                     "algorithmic_flop_per_launch_avg": round(fl / max(n, 1) / 1e9, 2)}
-        per = {t: summarise(t) for t in names}
-        dom = max(per, key=lambda t: per[t]["share_of_step_time"])       # the kernel the step spends most time in
-        traffic, tsrc = pmc_traffic(pmc_keys[dom])
-        roof = {"bound": "mfma", "kernel": names[dom], "achieved": per[dom]["achieved"], "peak": PEAK_BF16_TFLOPS,
+        tags = sorted({p[3] for p in prof})
+        per = {t: summarise(t) for t in tags}
+        big = [t for t in tags if t in fam]                              # the large-tile MFMA kernels
+        dom = max(big, key=lambda t: per[t]["share_of_step_time"])       # the kernel the step spends most time in
+        traffic, tsrc = pmc_traffic(fam[dom][1])
+        roof = {"bound": "mfma", "kernel": fam[dom][0], "achieved": per[dom]["achieved"], "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": per[dom]["frac"], "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": tsrc, "launches": per[dom]["launches"], "avg_launch_us": per[dom]["avg_launch_us"],
                 "event_steps": 1, "share_of_step_time": per[dom]["share_of_step_time"],
                 "algorithmic_flop_per_launch_avg": per[dom]["algorithmic_flop_per_launch_avg"],
-                "note": "HIP events on the launch stream around every launch of the last timed step; the backward pass "
+                "note": "HIP events on the launch stream around every conv launch of the last timed step; the backward pass "
                         "runs two streams, so backward launches share the CUs with kernels of the other stream; "
-                        "forward_only = the gather-GEMM's forward launches, which run alone",
-                "other_kernels": {names[t].split(" ")[0]: per[t] for t in names if t != dom},
-                "forward_only": summarise("gemm128", "conv_fwd"),
+                        "forward_only = the same kernel family over its forward launches, which run alone",
+                "other_kernels": {(fam[t][0] if t in fam else t).split(" ")[0]: per[t] for t in tags if t != dom},
+                "forward_only": summarise("conv_gather_gemm(global weight fragments)", "conv_fwd"),
                 "whole_step_conv_tflops": round(ips / world * 3 * FLOP_PER_IMAGE_FWD * (args.size / 608) ** 2 / 1e12, 1)}
+        if world == 1:
+            roof["per_layer"] = per_layer_bench(dev, args.size, args.batch)
     out = {
         "metric": "images/sec (train step, 608x608, bs/GPU=16)", "value": round(ips, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),

@@ -33,6 +33,10 @@ extern "C" {
 const char* mgd_last_error(void);
 int mgd_version(void);
 
+/* Name of the kernel family this thread's last launch went to, e.g. "conv_gather_gemm(counted pipeline, ping-pong)":
+ * measurement code tags its event brackets with it (bench.py).  No reference counterpart. */
+const char* mgd_last_kernel(void);
+
 /* Diagnostic only (tools/stamp_gemm9.py): reads and clears the 3 x 8 phase-time accumulators of the stamped build of the
  * gather-GEMM (MGD_DBG=4096).  No reference counterpart. */
 int mgd_debug_stamps(unsigned long long* out24);

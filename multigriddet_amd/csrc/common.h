@@ -20,8 +20,10 @@ int mgd_set_error(int code, const char* fmt, ...);
     if (!(cond)) return mgd_set_error(MGD_EINVAL, __VA_ARGS__); \
   } while (0)
 
+extern thread_local const char* mgd_last_launch_name;     // error.cpp: the kernel family of this thread's last launch
 #define MGD_CHECK_LAUNCH(name)                                                              \
   do {                                                                                      \
+    mgd_last_launch_name = name;                                                            \
     hipError_t e__ = hipGetLastError();                                                     \
     if (e__ != hipSuccess) return mgd_set_error(MGD_ELAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
   } while (0)

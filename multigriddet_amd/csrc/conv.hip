@@ -3825,10 +3825,14 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
   if (w4 < 0) { const char* e = getenv("MGD_WGRAD4"); w4 = e ? atoi(e) : 1; }
   const bool lin = d->in_stride == 1 && d->Hs == d->Hg && d->Ws == d->Wg &&
                    (long long)a.chunk * (co > ci ? co : ci) * 2 < (1ll << 31) && d->Hg * d->Wg <= 64 * 1024;
-  if (w4 && lin && co > 64 && ci > 64 && wtile == 0) launch_wgrad4<2, 2, 4, 4>(a, st);
-  else if (w4 && lin && co > 64 && ci > 64 && wtile == 1) launch_wgrad4<2, 2, 4, 2>(a, st);
-  else if (w4 && lin && co > 32 && ci > 32 && !(co > 64 && ci > 64)) launch_wgrad4<2, 2, 2, 2>(a, st);
-  else if (co > 64 && ci > 64 && wtile == 1) launch_wgrad<2, 2, 4, 2>(a, st);
+  if (w4 && lin && co > 32 && ci > 32 && (wtile <= 1 || !(co > 64 && ci > 64))) {
+    if (co > 64 && ci > 64 && wtile == 0) launch_wgrad4<2, 2, 4, 4>(a, st);
+    else if (co > 64 && ci > 64) launch_wgrad4<2, 2, 4, 2>(a, st);
+    else launch_wgrad4<2, 2, 2, 2>(a, st);
+    MGD_CHECK_LAUNCH("conv_wgrad(descriptor-addressed)");
+    return MGD_OK;
+  }
+  if (co > 64 && ci > 64 && wtile == 1) launch_wgrad<2, 2, 4, 2>(a, st);
   else if (co > 64 && ci > 64 && wtile == 2) launch_wgrad<2, 2, 2, 4>(a, st);   // 64 x 128 (slower)
   else if (co > 64 && ci > 64) launch_wgrad<2, 2, 4, 4>(a, st);
   else if (co > 32 && ci > 32) launch_wgrad<2, 2, 2, 2>(a, st);

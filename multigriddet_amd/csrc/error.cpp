@@ -14,5 +14,8 @@ int mgd_set_error(int code, const char* fmt, ...) {
   return code;
 }
 
+thread_local const char* mgd_last_launch_name = "";
+
 extern "C" const char* mgd_last_error(void) { return g_err; }
+extern "C" const char* mgd_last_kernel(void) { return mgd_last_launch_name; }
 extern "C" int mgd_version(void) { return 1; }

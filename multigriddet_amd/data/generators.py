@@ -63,60 +63,80 @@ def load_annotation_lines(path, shuffle=False):
     return lines
 
 
-def parse_annotation_line(line):
-    """'path x1,y1,x2,y2,cls ...' (reference generators.py:2425-2429) -> (path, boxes [n,5])."""
-    parts = line.split()
-    boxes = [list(map(float, p.split(",")))[:5] for p in parts[1:] if p]
-    boxes = [b + [0.0] * (5 - len(b)) for b in boxes]
-    boxes = np.array([b for b in boxes if any(v != 0 for v in b)], np.float32).reshape(-1, 5)
-    return parts[0], boxes
+from ..host_io import letterbox, load_image, parse_annotation_line, tune_host_allocators as _tune_host_allocators  # noqa: E402,F401
 
 
-_ALLOC_TUNED = False
+class _ProcessLoader:
+    """`num_workers` loader PROCESSES (python -m multigriddet_amd.host_io: no torch, no GPU) behind one connection each, a
+    shared-memory ring of batch buffers, and one feeder thread per worker that does nothing but send a task and wait for
+    its answer.  The trainer's process is left with its own Python work: enqueueing ~450 kernel launches per step needs
+    about half of a 13 ms step's GIL time, and decoding in threads of the same interpreter (np.asarray of a PIL image,
+    batch assembly, ... hold the GIL) stretched the step from 13.4 to 18.3 ms with the loader itself needing 11.9 ms per
+    batch - the two sides were serialised by the interpreter lock, not by the machine."""
 
+    def __init__(self, num_workers, slots, slot_bytes):
+        import queue
+        import secrets
+        import subprocess
+        import sys
+        import tempfile
+        import threading
+        from multiprocessing import shared_memory
+        from multiprocessing.connection import Listener
+        self.slot_bytes = int(slot_bytes)
+        self.shm = shared_memory.SharedMemory(create=True, size=int(slots) * self.slot_bytes)
+        self.tasks = queue.Queue()
+        self.dir = tempfile.mkdtemp(prefix="mgd_loader_")
+        address = os.path.join(self.dir, "sock")
+        key = secrets.token_bytes(16)
+        self.listener = Listener(address, family="AF_UNIX", authkey=key)
+        env = dict(os.environ)
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        self.procs = [subprocess.Popen([sys.executable, "-m", "multigriddet_amd.host_io", address, key.hex(), self.shm.name],
+                                       env=env, close_fds=True) for _ in range(num_workers)]
+        self.conns = [self.listener.accept() for _ in range(num_workers)]
+        self.threads = [threading.Thread(target=self._feed, args=(c,), daemon=True, name=f"mgd-loader-{i}")
+                        for i, c in enumerate(self.conns)]
+        for t in self.threads:
+            t.start()
 
-def _tune_host_allocators():
-    """The loader threads allocate and free megabyte-sized image buffers at a high rate.  glibc serves those with
-    mmap/munmap (every buffer page-faults in again, and the threads serialise on the process's address-space lock) and
-    Pillow frees its image arenas at once: sixteen 608x608 PNGs took 78 ms on 8 threads, 28 ms with both caches on."""
-    global _ALLOC_TUNED
-    if _ALLOC_TUNED:
-        return
-    _ALLOC_TUNED = True
-    try:
-        from PIL import Image
-        Image.core.set_blocks_max(256)                 # keep freed 16-MiB image blocks for reuse
-    except Exception:
-        pass
-    try:
-        import ctypes
-        libc = ctypes.CDLL("libc.so.6")
-        libc.mallopt(-3, 1 << 30)                      # M_MMAP_THRESHOLD: image-sized buffers from the heap
-        libc.mallopt(-1, 1 << 30)                      # M_TRIM_THRESHOLD: and the heap keeps them
-    except Exception:
-        pass
+    def _feed(self, conn):
+        while True:
+            item = self.tasks.get()
+            if item is None:
+                return
+            task, done = item
+            try:
+                conn.send(task)
+                done(conn.recv())
+            except (EOFError, OSError) as e:
+                done((b"", 0, f"loader worker died: {e}"))
+                return
 
-
-def letterbox(image, boxes, target_hw, fill=0, dtype=np.float32):
-    """Aspect-preserving resize (bicubic) + centred pad; boxes mapped along.  Training pads with zeros
-    (tf.image.pad_to_bounding_box, reference generators.py:167-209); inference pads with 128
-    (utils/preprocessing.py:46) - pass fill accordingly."""
-    from PIL import Image
-    th, tw = target_hw
-    w, h = image.size
-    r = min(tw / w, th / h)
-    nw, nh = max(1, int(round(w * r))), max(1, int(round(h * r)))
-    ox, oy = (tw - nw) // 2, (th - nh) // 2
-    if (nw, nh) == (tw, th):
-        canvas = image.resize((nw, nh), Image.BICUBIC)          # fills the frame: no pad to paste into
-    else:
-        canvas = Image.new("RGB", (tw, th), (fill, fill, fill))
-        canvas.paste(image.resize((nw, nh), Image.BICUBIC), (ox, oy))
-    out = boxes.copy()
-    if len(out):
-        out[:, [0, 2]] = out[:, [0, 2]] * r + ox
-        out[:, [1, 3]] = out[:, [1, 3]] * r + oy
-    return np.asarray(canvas, dtype), out
+    def close(self):
+        for _ in self.threads:
+            self.tasks.put(None)
+        for c in self.conns:
+            try:
+                c.send(None)
+                c.close()
+            except OSError:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:
+                p.kill()
+        try:
+            self.listener.close()
+            self.shm.close()
+            self.shm.unlink()
+            import shutil
+            shutil.rmtree(self.dir, ignore_errors=True)
+        except Exception:
+            pass
+        self.procs, self.conns, self.threads = [], [], []
 
 
 class MultiGridDataGenerator:
@@ -127,7 +147,7 @@ class MultiGridDataGenerator:
                  num_workers: int = 8, mosaic_prob: float = 0.3, mixup_prob: float = 0.1,
                  max_boxes_per_image: int = 100, seed: int = 0, gridmask_prob: float = 0.1,
                  host_augment: Optional[bool] = None, native_multiscale: bool = False,
-                 shape_seed: Optional[int] = None, **kwargs):
+                 shape_seed: Optional[int] = None, worker_mode: Optional[str] = None, **kwargs):
         if enhance_augment not in (None, "mosaic"):
             raise ValueError(f"enhance_augment={enhance_augment!r}: only None or 'mosaic' exist (reference generators.py:1505)")
         self.annotation_lines = list(annotation_lines)
@@ -150,6 +170,10 @@ class MultiGridDataGenerator:
         self.rng_shuffle, self.rng_host, self.rng = (np.random.default_rng(c) for c in ss)
         self.rng_shape = np.random.default_rng(np.random.SeedSequence([int(seed if shape_seed is None else shape_seed), 7]))
         self.prefetch_factor = max(0, int(prefetch_factor))
+        # "process": the prefetching iterator decodes in worker processes (default with more than one worker); "thread":
+        # in the thread pool of this process (what gen[i] / load_batch always use)
+        self.worker_mode = worker_mode or os.environ.get("MGD_LOADER", "process")
+        self._ploader = None
         self.host_augment = augment if host_augment is None else bool(host_augment)
         self.native_multiscale = bool(native_multiscale)
         self.num_workers = max(1, int(num_workers))
@@ -180,26 +204,9 @@ class MultiGridDataGenerator:
             self.rng_shuffle.shuffle(self.indexes)
 
     def _load(self, line, target_shape=None, out_shape=None, seed=None):
-        """One image: decode -> letterbox to target_shape (-> bilinear resize to out_shape when they differ, the
-        reference's cv2.resize at :1655) -> per-image augmentation chain.  Thread-safe: its own Generator."""
-        from PIL import Image
+        """One image (host_io.load_image): decode -> letterbox -> optional resize -> per-image augmentation.  Thread-safe."""
         target_shape = tuple(target_shape or self.input_shape)
-        out_shape = tuple(out_shape or target_shape)
-        path, boxes = parse_annotation_line(line)
-        img = Image.open(path).convert("RGB")
-        # 8-bit until something needs fractions: without host augmentation the batch crosses PCIe as uint8 (a quarter of
-        # the bytes) and is widened on the device
-        im, bx = letterbox(img, boxes, target_shape, fill=0, dtype=np.uint8)
-        if out_shape != target_shape:
-            oh, ow = out_shape
-            im = np.asarray(Image.fromarray(im).resize((ow, oh), Image.BILINEAR))
-            if len(bx):
-                bx[:, [0, 2]] *= ow / target_shape[1]
-                bx[:, [1, 3]] *= oh / target_shape[0]
-        if self.host_augment:
-            from . import host_aug
-            im, bx = host_aug.augment_image(np.random.default_rng(seed), im.astype(np.float32), bx, out_shape)
-        return im, bx
+        return load_image(line, target_shape, tuple(out_shape or target_shape), seed, self.host_augment)
 
     def next_shape(self):
         """Sequence-path multi-scale (reference :1627-1633): every rescale_interval-th batch draws a shape."""
@@ -220,17 +227,11 @@ class MultiGridDataGenerator:
         """Host part: returns (images in the uint8 range [B,H,W,3] - uint8, or fp32 after host augmentation -, boxes
         [B, capacity, 5]).  The last batch of an epoch is filled up from the start of the (shuffled) index list, so
         every batch has batch_size images.  pinned: page-locked image buffer (asynchronous host-to-device copy)."""
-        idx = self.indexes[i * self.batch_size:(i + 1) * self.batch_size]
-        if len(idx) < self.batch_size:
-            idx = np.concatenate([idx, np.resize(self.indexes, self.batch_size - len(idx))])
         cap = self.max_boxes_per_image * (self._calculate_expansion_factor() if self.augment else 1)
-        target = tuple(self.next_shape())
-        out = target if self.native_multiscale else self.input_shape
+        jobs, out = self._batch_jobs(i)
         H, W = out
         images = self._host_buffer((self.batch_size, H, W, 3), np.float32 if self.host_augment else np.uint8, pinned)
         boxes = np.zeros((self.batch_size, cap, 5), np.float32)
-        seeds = self.rng_host.integers(0, 2 ** 31 - 1, size=len(idx))
-        jobs = [(self.annotation_lines[k], target, out, int(sd)) for k, sd in zip(idx, seeds)]
         pool = self._pool()
         results = list(pool.map(lambda a: self._load(*a), jobs)) if pool else [self._load(*a) for a in jobs]
         for j, (im, bx) in enumerate(results):
@@ -280,19 +281,106 @@ class MultiGridDataGenerator:
             return
         yield from self._iter_prefetch()
 
+    def close(self):
+        """Stops the loader processes and frees their shared memory (also on garbage collection)."""
+        if self._ploader is not None:
+            self._ploader.close()
+            self._ploader = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _batch_jobs(self, i):
+        """Random draws and job list of batch i - always taken in batch order, by one thread."""
+        idx = self.indexes[i * self.batch_size:(i + 1) * self.batch_size]
+        if len(idx) < self.batch_size:
+            idx = np.concatenate([idx, np.resize(self.indexes, self.batch_size - len(idx))])
+        target = tuple(self.next_shape())
+        out = target if self.native_multiscale else self.input_shape
+        seeds = self.rng_host.integers(0, 2 ** 31 - 1, size=len(idx))
+        return [(self.annotation_lines[k], target, out, int(sd)) for k, sd in zip(idx, seeds)], out
+
     def _iter_prefetch(self):
-        """One epoch with the host path running ahead: a producer thread calls load_batch(i) in order (fanning the images
-        of a batch out to the worker pool) into a queue of `prefetch_factor` pinned batches; the consumer uploads batch
-        i+1 on a copy stream before it hands out batch i, so decode, letterbox, host augmentation and the PCIe copy all
-        run under the GPU's step.  Random draws: see __init__ (identical to the synchronous path)."""
+        """One epoch with the host path running ahead: batch i+1.. is decoded / letterboxed / augmented in the background
+        (worker processes by default, see _ProcessLoader; MGD_LOADER=thread: a producer thread on the thread pool) into a
+        ring of `prefetch_factor` host batches, and the consumer uploads batch i+1 on a copy stream before it hands out
+        batch i - so decode, host augmentation and the PCIe copy all run under the GPU's step.  Random draws: see __init__
+        (identical to the synchronous path)."""
         import queue
         import threading
         n = len(self)
         q = queue.Queue(maxsize=self.prefetch_factor)
         stop = threading.Event()
+        cap = self.max_boxes_per_image * (self._calculate_expansion_factor() if self.augment else 1)
+        use_proc = self.worker_mode == "process" and self.num_workers > 1
+        dtype = np.float32 if self.host_augment else np.uint8
+        if use_proc and self._ploader is None:
+            hmax = max(self.input_shape[0], 672 if self.native_multiscale else 0)
+            wmax = max(self.input_shape[1], 672 if self.native_multiscale else 0)
+            slot = self.batch_size * hmax * wmax * 3 * np.dtype(dtype).itemsize
+            self._ploader = _ProcessLoader(self.num_workers, self.prefetch_factor + 2, slot)
+        free_slots = queue.Queue()
+        if use_proc:
+            for k in range(self.prefetch_factor + 2):
+                free_slots.put(k)
+
+        def make_done(boxes, state, fin):
+            """Completion callback of ONE batch (its own boxes / counters: closures bind names, not values)."""
+            lock = threading.Lock()
+
+            def done(res, j):
+                raw, cnt, err = res
+                with lock:
+                    if err is None and cnt > self.max_boxes_per_image:
+                        err = f"image has {cnt} boxes, capacity {self.max_boxes_per_image}"
+                    if err is not None:
+                        state["err"] = err
+                    elif cnt:
+                        boxes[j, :cnt] = np.frombuffer(raw, np.float32).reshape(cnt, 5)
+                    state["left"] -= 1
+                    if state["left"] == 0:
+                        fin.set()
+            return done
+
+        def produce_proc():
+            pl = self._ploader
+            for i in range(n):
+                if stop.is_set():
+                    return
+                jobs, (H, W) = self._batch_jobs(i)
+                slot = None
+                while slot is None and not stop.is_set():
+                    try:
+                        slot = free_slots.get(timeout=0.1)
+                    except queue.Empty:
+                        pass
+                if slot is None:
+                    return
+                per = H * W * 3 * np.dtype(dtype).itemsize
+                boxes = np.zeros((self.batch_size, cap, 5), np.float32)
+                state = {"left": len(jobs), "err": None}
+                fin = threading.Event()
+                done = make_done(boxes, state, fin)
+                for j, (line, target, out, seed) in enumerate(jobs):
+                    pl.tasks.put(((slot * pl.slot_bytes + j * per, line, target, out, seed, self.host_augment),
+                                  (lambda res, j=j, d=done: d(res, j))))
+                # the next batch's tasks may go out as soon as a slot is free: completion is awaited in order by a helper
+                item = (slot, (self.batch_size, H, W, 3), boxes, state, fin)
+                while not stop.is_set():
+                    try:
+                        q.put(item, timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
 
         def produce():
             try:
+                if use_proc:
+                    produce_proc()
+                    return
                 for i in range(n):
                     if stop.is_set():
                         return
@@ -316,7 +404,18 @@ class MultiGridDataGenerator:
             item = q.get()
             if isinstance(item, BaseException):
                 raise item
-            images, boxes = item
+            if use_proc:
+                slot, shape, boxes, state, fin = item
+                fin.wait()
+                if state["err"] is not None:
+                    raise RuntimeError(state["err"])
+                view = np.ndarray(shape, dtype, buffer=self._ploader.shm.buf, offset=slot * self._ploader.slot_bytes)
+                images = self._host_buffer(shape, dtype, True)
+                np.copyto(images, view)                 # shared memory -> page-locked memory (no GIL while it copies)
+                del view
+                free_slots.put(slot)
+            else:
+                images, boxes = item
             with torch.cuda.stream(cs):
                 img = torch.from_numpy(images).cuda(non_blocking=True)
                 bx = torch.from_numpy(boxes).cuda(non_blocking=True)

@@ -42,7 +42,9 @@ class MultiGridInference:
         self.input_shape = tuple(self.model_config["model"]["preset"].get("input_shape", [608, 608, 3])[:2])
         self.decoder = MultiGridDecoder(self.anchors, len(self.class_names), self.input_shape, rescore_confidence=True)
         self.model = build_model_for_inference(self.full_config, weights_path)
-        if self.config.get("fold_bn", False):      # opt-in (not a reference key): BatchNorm folded into the convs
+        # BatchNorm folded into the convs (one launch per DarknetConv2D_BN_Leaky): the default for inference - 4 534 against
+        # 3 661 images/s at batch 16; `fold_bn: false` (not a reference key) keeps the separate BatchNorm launches
+        if self.config.get("fold_bn", True):
             self.model.fold_bn(True)
         self.letterbox = DeviceLetterbox(self.input_shape)
         # "host": the reference's PIL letterbox on the CPU (kept for A/B; results are identical)

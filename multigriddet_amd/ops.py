@@ -29,10 +29,7 @@ def _launch_gemm(d, what):
     e0.record()
     L.check(lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), what)
     e1.record()
-    variant = "gemm128" if d.Co_pad % 128 == 0 else ("gemm64" if d.Co_pad % 64 == 0 else "gemm32")
-    nb, nk = (d.Co_pad // 128) * -(-(d.N * d.Hg * d.Wg) // 128), d.K_pad // 64
-    if variant == "gemm128" and not d.dst_f32 and nk >= 4 and nb <= 256:
-        variant = "gemm128pc"        # dispatched to the producer/consumer kernel (same rule as conv.hip)
+    variant = lib.mgd_last_kernel().decode()      # the kernel family the library dispatched this launch to
     PROFILE.append((e0, e1, 2.0 * d.N * d.Hg * d.Wg * d.ntaps * d.Ci * d.Co, variant, what))
 
 
@@ -282,7 +279,7 @@ def conv_wgrad(x, dy, dw, k, s, splits=None):
     e0.record()                      # on the stream the launch goes to (the weight-gradient side stream in the engine)
     L.check(L.load().mgd_conv_wgrad(C.byref(d), L.stream_ptr()), "conv_wgrad")
     e1.record()
-    variant = "wgrad128" if (Co > 64 and Ci > 64) else ("wgrad_patch" if (k == 3 and Ci in (32, 64) and Wo >= 16) else "wgrad_small")
+    variant = L.load().mgd_last_kernel().decode()
     PROFILE.append((e0, e1, 2.0 * N * Ho * Wo * k * k * Ci * Co, variant, "conv_wgrad"))
     return dw
 

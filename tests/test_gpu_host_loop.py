@@ -424,11 +424,15 @@ def test_prefetching_generator_hides_the_host_path(tmp_path):
         return MultiGridDataGenerator(lines, B, (S, S), anchors, 80, augment=augment, enhance_augment="mosaic" if augment else None,
                                       mosaic_prob=0.5, mixup_prob=0.5, gridmask_prob=0.5, shuffle=True, seed=3,
                                       num_workers=nw, prefetch_factor=prefetch, host_augment=False, max_boxes_per_image=10)
-    # (1) identical batches, device augmentation on
+    # (1) identical batches, device augmentation on: synchronous path, loader processes, loader threads
     a, b = gen(0, True), gen(3, True)
-    for (xa, _), (xb, _) in zip(a, b):
-        for ta, tb_ in zip(xa, xb):
-            assert torch.equal(ta, tb_)
+    c = MultiGridDataGenerator(lines, B, (S, S), anchors, 80, augment=True, enhance_augment="mosaic", mosaic_prob=0.5,
+                               mixup_prob=0.5, gridmask_prob=0.5, shuffle=True, seed=3, num_workers=nw, prefetch_factor=3,
+                               host_augment=False, max_boxes_per_image=10, worker_mode="thread")
+    for (xa, _), (xb, _), (xc, _) in zip(a, b, c):
+        for ta, tb_, tc_ in zip(xa, xb, xc):
+            assert torch.equal(ta, tb_) and torch.equal(ta, tc_)
+    b.close()
     # (2) timing
     dev = torch.device("cuda:0")
     net = Network(80, 3, dev, seed=0)
@@ -461,8 +465,10 @@ def test_prefetching_generator_hides_the_host_path(tmp_path):
                 cnt += 1
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / cnt
-    epochs(gen(4, False), 1)
-    t_pre = epochs(gen(4, False), 3)
+    gp = gen(4, False)
+    epochs(gp, 1)                                      # starts the loader processes, warms the allocator caches
+    t_pre = epochs(gp, 3)
+    gp.close()
     t_sync = epochs(gen(0, False), 2)
     print(f"\nstep: synthetic {t_syn * 1e3:.2f} ms, prefetching loader {t_pre * 1e3:.2f} ms, synchronous loader "
           f"{t_sync * 1e3:.2f} ms; host alone {t_host * 1e3:.2f} ms per batch ({nw} threads)")

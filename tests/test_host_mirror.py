@@ -131,3 +131,60 @@ def test_resample_tables_reproduce_pil_bicubic_exactly():
     for i in range(int(g["n"])):
         mh, mw = (int(v) for v in g[f"model_hw{i}"])
         assert np.array_equal(op.letterbox(g[f"img{i}"], (mh, mw), resample_tables, letterbox_geometry), g[f"boxed{i}"])
+
+
+def test_process_loader_matches_in_process_decode(tmp_path):
+    """The loader processes of the prefetching generator (python -m multigriddet_amd.host_io, no torch inside) return,
+    through the shared-memory batch ring, exactly what host_io.load_image computes in this process - with and without the
+    per-image host augmentation (seeded) - and the worker module really imports without torch."""
+    import subprocess
+    import sys
+    import threading
+    import numpy as np
+    from PIL import Image
+    from multigriddet_amd.data.generators import _ProcessLoader
+    from multigriddet_amd.host_io import load_image
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(6):
+        h, w = (90, 120) if i % 2 else (128, 100)
+        img = (rng.random((h, w, 3)) * 255).astype(np.uint8)
+        path = str(tmp_path / f"im{i}.png")
+        Image.fromarray(img).save(path)
+        lines.append(f"{path} 10,12,{40 + i},50,{i} 5,6,30,31,7")
+    out = subprocess.run([sys.executable, "-c", "import sys, multigriddet_amd.host_io; print('torch' in sys.modules)"],
+                         capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.stdout.strip() == "False", out.stdout + out.stderr
+    S = 96
+    for aug, dtype in ((False, np.uint8), (True, np.float32)):
+        per = S * S * 3 * np.dtype(dtype).itemsize
+        pl = _ProcessLoader(2, 1, len(lines) * per)
+        try:
+            res = [None] * len(lines)
+            fin = threading.Semaphore(0)
+
+            def done(r, j):
+                res[j] = r
+                fin.release()
+            for j, line in enumerate(lines):
+                pl.tasks.put(((j * per, line, (S, S), (S, S), 100 + j, aug), (lambda r, j=j: done(r, j))))
+            for _ in lines:
+                assert fin.acquire(timeout=120)
+            for j, line in enumerate(lines):
+                raw, cnt, err = res[j]
+                assert err is None, err
+                im_ref, bx_ref = load_image(line, (S, S), (S, S), 100 + j, aug)
+                got = np.ndarray((S, S, 3), dtype, buffer=pl.shm.buf, offset=j * per).copy()
+                assert im_ref.dtype == dtype and np.array_equal(got, im_ref)
+                assert cnt == len(bx_ref) and np.array_equal(np.frombuffer(raw, np.float32).reshape(cnt, 5), bx_ref)
+        finally:
+            pl.close()
+
+
+def test_prefetch_iterator_machinery_on_cpu():
+    """The prefetching iterator (loader processes and loader threads, two epochs, multi-scale draws, host augmentation on and
+    off) yields the same batches in both modes; torch.cuda is stubbed out inside the harness interpreter."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "prefetch_cpu_harness.py")], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "aug True ok 6" in out.stdout and "aug False ok 6" in out.stdout, out.stdout + out.stderr
