@@ -91,6 +91,14 @@ typedef struct mgd_conv_desc {
    * act_slope != 0 applies LeakyReLU(act_slope) to (acc + bias) before the optional `addend` (= the residual input),
    * i.e. the whole DarknetConv2D_BN_Leaky (+ Add) of models/layers.py:88-95 in one launch.  bf16 output only. */
   float act_slope;
+  /* Split-K for launches with few output tiles and a long contraction (batch-1 inference on the 19x19 / 38x38 maps: 24-48
+   * tiles of 72 / 36 serial K-steps): splitk > 1 cuts K into `splitk` ranges, every (tile, range) block stores an fp32
+   * partial tile into partial[range][N*Hd*Wd*Co] (plain stores: deterministic), and a second launch adds the ranges, applies
+   * bias / act_slope / addend and writes bf16 `dst`.  bf16 output without stats / bn_y only; partial_bytes >=
+   * splitk * N*Hd*Wd*Co * 4.  0 or 1: off. */
+  int32_t splitk;
+  float* partial;
+  int64_t partial_bytes;
 } mgd_conv_desc;
 
 int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream);

@@ -29,6 +29,7 @@ class ConvDesc(C.Structure):
         ("K_pad", C.c_int32), ("Co_pad", C.c_int32), ("dst_f32", C.c_int32), ("stats_replicas", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_mean", C.c_void_p),
         ("bn_invstd", C.c_void_p), ("bn_sums", C.c_void_p), ("bn_slope", C.c_float), ("act_slope", C.c_float),
+        ("splitk", C.c_int32), ("partial", C.c_void_p), ("partial_bytes", C.c_int64),
     ]
 
 

@@ -45,6 +45,8 @@ struct GemmArgs {
   float bn_slope;
   float act_slope;   // != 0: LeakyReLU on (acc + bias) before the addend (BatchNorm-folded inference)
   unsigned rowmask, colmask;   // conv_gemm9_kernel: 3 x 9 bits, the taps with dh + 1 == j / dw + 1 == j (bits 9j .. 9j+8)
+  int splitk;                  // conv_gemm8_kernel: K ranges per tile (blocks = nblk * splitk); fp32 partial tiles go to
+  long long slab_elems;        //   (float*)dst + range * slab_elems
 };
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * ROWB + ((kc ^ (row & 7)) << 4); }
@@ -894,11 +896,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / WP, wp = wave % WP;
-  const int L = xcd_remap(blockIdx.x, a.nblk);
+  // split-K (a.splitk > 1): block = (tile, K range); its fp32 partial tile goes to slab `range` of the workspace
+  const int krange = a.splitk > 1 ? (int)blockIdx.x / a.nblk : 0;
+  const int L = xcd_remap(a.splitk > 1 ? (int)blockIdx.x - krange * a.nblk : (int)blockIdx.x, a.nblk);
   const int tc = L % a.tilesC, tp = L / a.tilesC;
   const int co0 = tc * BNC, pix0 = tp * BMP;
   if (ABL && (a.dbg & 1024)) return;                  // dispatch cost alone
-  const int nk = (ABL && (a.dbg & 2048)) ? 0 : a.K_pad / BK;   // 2048: prologue + epilogue, no K-loop
+  const int nk_all = a.K_pad / BK;
+  const int kper = a.splitk > 1 ? (nk_all + a.splitk - 1) / a.splitk : nk_all;
+  const int ks_lo = krange * kper;
+  const int nk = (ABL && (a.dbg & 2048)) ? 0 : min(nk_all, ks_lo + kper);   // 2048: prologue + epilogue, no K-loop
+  if (a.splitk > 1) a.dst = (void*)((float*)a.dst + (long long)krange * a.slab_elems);
 
   if (tid < BMP) {
     int m = pix0 + tid;
@@ -935,8 +943,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       }
     }
   }
-  int tap = (kc * 8) / a.Ci;
-  int cch = (kc * 8) - tap * a.Ci;
+  int tap = (kc * 8 + ks_lo * BK) / a.Ci;
+  int cch = (kc * 8 + ks_lo * BK) - tap * a.Ci;
   // out-of-image taps are fetched from a zero page (64-bit per-lane source addresses): conv_gemm2_kernel loads them from
   // offset 0 and overwrites the LDS slot with zeros afterwards, and in front of that ds_write hipcc puts s_waitcnt vmcnt(0)
   // (it may alias the LDS-DMA writes in flight) - harmless with two stages, but it drains any deeper ring on every K-step
@@ -975,7 +983,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   // weight fragments: block (tc, ks) = 1024 chunks of 16 B; this wave's eight start at wc*512.  NST register sets: the
   // set of step ks + NST - 1 is requested together with ring stage ks + NST - 1, so both operands have NST - 1 K-steps
   // to arrive (with a single step of distance the round trip of the weight loads sets the K-step, whatever the ring depth)
-  const uint4* wl = (const uint4*)a.wpk + ((size_t)tc * nk * 16 + (size_t)wc * (MT * 2)) * 64 + lane;
+  const uint4* wl = (const uint4*)a.wpk + ((size_t)tc * nk_all * 16 + (size_t)wc * (MT * 2)) * 64 + lane;
   bf16x8 af[NST][MT][2];
   auto load_a = [&](bf16x8 (&f)[MT][2], int ks) {
     const uint4* w = wl + (size_t)ks * 1024;
@@ -986,10 +994,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   };
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) { if (!abl_d) issue(s); load_a(af[s], s); }
+    if (ks_lo + s < nk) { if (!abl_d) issue(s); load_a(af[s], ks_lo + s); }
 
   constexpr int GRP = XCH + 2 * MT;                    // vector-memory instructions per stage: 4 LDS-DMA + 8 fragment loads
-  for (int ks0 = 0; ks0 < nk; ks0 += NST) {
+  for (int ks0 = ks_lo; ks0 < nk; ks0 += NST) {
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
       const int ks = ks0 + j;
@@ -1036,12 +1044,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   epi.template run<false, true>(a, acc, smem, row_dst, co0, tid);
 }
 
+// second launch of a split-K convolution: sum of the K ranges' fp32 partial tiles -> bias -> LeakyReLU -> + residual -> bf16
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ partial, int splitk, long long slab_elems,
+                                                              bf16_t* __restrict__ dst, const float* __restrict__ bias,
+                                                              const bf16_t* __restrict__ addend, float act_slope, int Co,
+                                                              long long total8) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= total8) return;
+  const long long e = q * 8;
+  const int c = (int)(e % Co);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = bias ? bias[c + j] : 0.f;
+  for (int s = 0; s < splitk; ++s) {
+    const f32x4 lo = *(const f32x4*)(partial + s * slab_elems + e), hi = *(const f32x4*)(partial + s * slab_elems + e + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] += lo[j]; v[4 + j] += hi[j]; }
+  }
+  if (act_slope != 0.f) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * act_slope;
+  }
+  if (addend) {
+    float g[8];
+    unpack8(*(const uint4*)(addend + e), g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += g[j];
+  }
+  *(uint4*)(dst + e) = pack8(v);
+}
+
 template <int NST, int WPE, int WC = 2>
 int launch_gemm8(GemmArgs& a, hipStream_t st) {
   a.tilesC = a.Co_pad / 128;
   a.nblk = a.tilesC * cdiv(a.M, 128);
   size_t ring = (size_t)NST * 128 * ROWB;
   size_t epi = a.dst_f32 ? (size_t)128 * (128 * 4 + 16) : (size_t)128 * (128 * 2 + 16) + 4 * 2 * 128 * 4;
+  const int grid8 = a.nblk * (a.splitk > 1 ? a.splitk : 1);
   a.aux = (int)(ring > epi ? ring : epi);
   size_t lds = (size_t)a.aux + 128 * 8 + 64;
   auto k = conv_gemm8_kernel<NST, WPE, false, WC>;
@@ -1051,8 +1090,8 @@ int launch_gemm8(GemmArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv_gemm8_kernel<NST, WPE, true, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  if (a.dbg & 0xFE0) hipLaunchKernelGGL((conv_gemm8_kernel<NST, WPE, true, WC>), dim3(a.nblk), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL(k, dim3(a.nblk), dim3(256), lds, st, a);
+  if (a.dbg & 0xFE0) hipLaunchKernelGGL((conv_gemm8_kernel<NST, WPE, true, WC>), dim3(grid8), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(k, dim3(grid8), dim3(256), lds, st, a);
   return 0;
 }
 
@@ -3562,6 +3601,26 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   //    (1024->512 at 19x19, 184 tiles: 66 us against 108);
   //  * everything else: weights straight from global memory, three blocks per CU.
   if (d->Co_pad % 128 == 0) {
+    a.splitk = 0; a.slab_elems = 0;
+    if (d->splitk > 1) {
+      // few tiles, long contraction: K ranges to separate blocks, fp32 slabs, finalize launch (see mgd_conv_desc.splitk)
+      MGD_REQUIRE(!d->dst_f32 && !d->stats && !d->bn_y, "conv: split-K is for bf16 output without statistics / fused reductions");
+      MGD_REQUIRE(d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 && d->Hd == d->Hg && d->Wd == d->Wg,
+                  "conv: split-K needs a dense destination");
+      const long long slab = (long long)d->N * d->Hd * d->Wd * d->Co;
+      MGD_REQUIRE(d->partial && d->partial_bytes >= (int64_t)d->splitk * slab * 4, "conv: split-K workspace too small");
+      MGD_REQUIRE(d->splitk <= nk, "conv: more K ranges than K-steps");
+      GemmArgs p = a;
+      p.splitk = d->splitk; p.slab_elems = slab;
+      p.dst = d->partial; p.dst_f32 = 1; p.bias = nullptr; p.addend = nullptr; p.act_slope = 0.f;
+      launch_gemm8<2, 3, 4>(p, st);
+      MGD_CHECK_LAUNCH("conv_gather_gemm(split-K)");
+      const long long total8 = slab / 8;
+      hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)cdiv(total8, 256)), dim3(256), 0, st, (const float*)d->partial,
+                         d->splitk, slab, (bf16_t*)d->dst, d->bias, (const bf16_t*)d->addend, d->act_slope, d->Co, total8);
+      MGD_CHECK_LAUNCH("conv_gather_gemm(split-K)");
+      return MGD_OK;
+    }
     {
       // streaming ping-pong form (conv_gemm10_kernel): 256-channel blocks, K-loops of whole groups of 6 steps
       static int g10 = -1;
@@ -3610,8 +3669,10 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
       bool use9 = g9 > 0, force_pp = false;
       if (g9 < 0 && !d->dst_f32 && d->ntaps > 1 && d->Ci % 64 == 0 && nk >= 4) {
         const long long tiles128 = (long long)(d->Co_pad / 128) * cdiv(a.M, 128);
-        if (d->Co_pad % 256 == 0 && (nk >= 64 || (nk >= 36 && tiles128 <= 512))) { use9 = true; force_pp = true; }
-        else if (tiles128 <= 512 && nk <= 36) use9 = true;
+        // (both rules need enough tiles to occupy the chip: at batch 1 the 19 x 19 / 38 x 38 layers have 12-48 tiles and the
+        // producer/consumer kernel's 128-channel blocks spread them over twice as many CUs)
+        if (d->Co_pad % 256 == 0 && tiles128 >= 256 && (nk >= 64 || (nk >= 36 && tiles128 <= 512))) { use9 = true; force_pp = true; }
+        else if (tiles128 >= 128 && tiles128 <= 512 && nk <= 36) use9 = true;
       }
       if (use9 && !d->dst_f32 && ((d->ntaps == 1 && g9one) || (d->ntaps > 1 && d->Ci % 64 == 0)) && nk >= 2) {
         // Tile shape.  The K-loop is bound by the CU's vector-memory path (~25 B/clk delivered, weights + pixels), so the

@@ -4,6 +4,7 @@ Everything here takes/returns torch CUDA tensors and enqueues on torch's current
 activations NHWC bf16, master weights fp32 OHWI ([Co, kh*kw, Ci]), packed GEMM images bf16.
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -184,8 +185,36 @@ def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False, act_slope=0.
     dh, dw = taps_fwd(pk.k)
     d = _desc(x, pk.fwd if wimg is None else wimg, out, N, H, W, Ci, Ho, Wo, Ho, Wo, pk.co, pk.s, 1, (0, 0), dh, dw,
               pk.fwd_kpad, pk.fwd_copad, bias=bias, stats=stats, dst_f32=out_f32, act_slope=act_slope, addend=addend)
+    sp = splitk_factor(N * Ho * Wo, pk.fwd_copad, pk.fwd_kpad) if (stats is None and not out_f32 and SPLITK) else 1
+    if sp > 1:
+        # few output tiles, long contraction (small-batch inference on the 19 x 19 / 38 x 38 maps): K ranges on separate CUs
+        ws = _splitk_workspace(sp * N * Ho * Wo * pk.co * 4, x.device)
+        d.splitk, d.partial, d.partial_bytes = sp, ws.data_ptr(), ws.numel() * 4
     _launch_gemm(d, "conv_fwd")
     return out
+
+
+SPLITK = os.environ.get("MGD_SPLITK", "1") != "0"
+_SPLITK_WS = {}
+
+
+def splitk_factor(M, co_pad, k_pad):
+    """K ranges for a forward launch: 1 unless the launch has at most 96 tiles of 128 x 128 and at least 16 K-steps; then as
+    many ranges as keep >= 8 K-steps each and about 192 blocks in all (batch 1 at 608 x 608: 512 -> 1024 at 19 x 19 = 24 tiles
+    x 72 steps -> 8 ranges of 9; 256 -> 512 at 38 x 38 = 48 tiles x 36 steps -> 4 ranges of 9)."""
+    if co_pad % 128:
+        return 1
+    tiles, nk = (co_pad // 128) * -(-M // 128), k_pad // 64
+    if tiles > 96 or nk < 16:
+        return 1
+    return max(1, min(8, nk // 8, 192 // tiles))
+
+
+def _splitk_workspace(nbytes, device):
+    ws = _SPLITK_WS.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _SPLITK_WS[device] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    return ws
 
 
 def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):

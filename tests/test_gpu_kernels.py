@@ -303,6 +303,44 @@ def test_conv_bias_leaky_residual_epilogue(dev, N, H, W, Ci, Co, k, s):
     assert err <= 0.02 * ref.abs().max().item() + 1e-3, err
 
 
+@pytest.mark.parametrize("N,H,W,Ci,Co,k,s,splits", [(1, 19, 19, 512, 1024, 3, 1, 8), (1, 38, 38, 256, 512, 3, 1, 4),
+                                                    (2, 19, 19, 1024, 512, 1, 1, 2), (1, 13, 11, 256, 384, 3, 1, 4),
+                                                    (1, 38, 38, 512, 1024, 3, 2, 8)])
+def test_conv_split_k_matches_reference(dev, N, H, W, Ci, Co, k, s, splits):
+    """Split-K route of the forward convolution (few output tiles, long contraction: small-batch inference): K ranges on
+    separate blocks, fp32 partial slabs, a finalize launch with bias + LeakyReLU + residual.  ops.splitk_factor picks the
+    stated number of ranges at these shapes; the result equals the fp32 torch reference within the bf16 output rounding and
+    the single-launch route within one bf16 ulp of the larger operand scale (only the summation order differs); two calls
+    are bit-identical (plain stores, no atomics)."""
+    from multigriddet_amd import ops
+    g = torch.Generator().manual_seed(777 + Ci + Co + H)
+    x = bf(torch.randn(N, H, W, Ci, generator=g))
+    w = torch.randn(Co, k * k, Ci, generator=g) / (k * (Ci ** 0.5))
+    bias = torch.randn(Co, generator=g) * 0.5
+    pk = ops.PackedConv(Co, Ci, k, s, dev)
+    pk.refresh(w.to(dev))
+    Ho, Wo = (H // 2, W // 2) if s == 2 else (H, W)
+    assert ops.splitk_factor(N * Ho * Wo, pk.fwd_copad, pk.fwd_kpad) == splits
+    y_ref = _ref_conv(x, w, k, s) + bias
+    res = bf(torch.randn(*y_ref.shape, generator=g))
+    ref = torch.where(y_ref > 0, y_ref, 0.1 * y_ref) + res.float()
+    xd, bd, rd = x.to(dev), bias.to(dev), res.to(dev)
+    assert ops.SPLITK
+    out = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
+    assert ops.L.load().mgd_last_kernel() == b"conv_gather_gemm(split-K)"
+    out2 = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
+    ops.SPLITK = False
+    try:
+        single = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
+    finally:
+        ops.SPLITK = True
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    tol = 0.02 * ref.abs().max().item() + 1e-3
+    assert (out.float().cpu() - ref).abs().max().item() <= tol
+    assert (out.float() - single.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("N,H,W,Ci,Co,k,s", [(2, 20, 20, 64, 128, 3, 1), (2, 24, 24, 32, 64, 3, 2), (3, 19, 19, 256, 128, 1, 1),
                                              (2, 44, 36, 32, 64, 3, 1)])      # patch-form data gradient (64 -> 32)
 def test_dgrad_fused_bn_reduction(dev, N, H, W, Ci, Co, k, s):
