@@ -194,7 +194,10 @@ def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False, act_slope=0.
     return out
 
 
-SPLITK = os.environ.get("MGD_SPLITK", "1") != "0"
+# opt-in (MGD_SPLITK=1): measured at batch 1, 608 x 608 - the 19 x 19 3x3 launches 43 -> 25 us and the 38 x 38 ones 29.5 -> 25 us
+# (two launches each), the 1x1 ones 16 -> 19 us, the whole forward 1.146 -> 1.170 ms: per-launch fixed costs, not the serial
+# K-loop, set the latency of the 75-launch forward
+SPLITK = os.environ.get("MGD_SPLITK", "0") == "1"
 _SPLITK_WS = {}
 
 

@@ -325,15 +325,16 @@ def test_conv_split_k_matches_reference(dev, N, H, W, Ci, Co, k, s, splits):
     res = bf(torch.randn(*y_ref.shape, generator=g))
     ref = torch.where(y_ref > 0, y_ref, 0.1 * y_ref) + res.float()
     xd, bd, rd = x.to(dev), bias.to(dev), res.to(dev)
-    assert ops.SPLITK
-    out = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
-    assert ops.L.load().mgd_last_kernel() == b"conv_gather_gemm(split-K)"
-    out2 = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
-    ops.SPLITK = False
+    was = ops.SPLITK
+    ops.SPLITK = True                                  # opt-in route (MGD_SPLITK=1)
     try:
+        out = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
+        assert ops.L.load().mgd_last_kernel() == b"conv_gather_gemm(split-K)"
+        out2 = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
+        ops.SPLITK = False
         single = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
     finally:
-        ops.SPLITK = True
+        ops.SPLITK = was
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
     tol = 0.02 * ref.abs().max().item() + 1e-3
