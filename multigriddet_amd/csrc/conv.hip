@@ -51,6 +51,38 @@ struct GemmArgs {
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * ROWB + ((kc ^ (row & 7)) << 4); }
 
+// Row tables of one pixel tile, one pixel per thread (tid < BMP): the destination element offset of the pixel's output row
+// (-1 past the end) and, for the gather, the byte offset of its centre source pixel with the 9-bit set of taps that stay
+// inside the image = taps with a valid row AND a valid column (a.rowmask / a.colmask: the taps by dh + 1 / dw + 1).
+// Round 3: every gather-GEMM builds its staged rows from these tables - before, each thread derived (image, row, column) of
+// each of its 2-4 staged rows itself and looped over the taps: two divisions and a 9-iteration loop per row, 1 500 vector
+// instructions per wave and tile, as many as an 18-step K-loop (PMC: profiles/r03_pmc_instruction_mix.txt).
+__device__ __forceinline__ void make_row_tables(const GemmArgs& a, int pix0, int tid, int bmp, long long* row_dst, uint2* row_src) {
+  if (tid < bmp) {
+    const int m = pix0 + tid;
+    long long off = -1;
+    unsigned xo = 0, vm = 0;
+    if (m < a.M) {
+      const int hw = a.Hg * a.Wg;
+      const int n = m / hw, rem = m - n * hw;
+      const int ig = rem / a.Wg, jg = rem - ig * a.Wg;
+      const int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
+      off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
+      const int hs = ig * a.in_stride, ws = jg * a.in_stride;
+      xo = (unsigned)(((((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci) * 2);
+      unsigned rsel = 0, csel = 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if ((unsigned)(hs + j - 1) < (unsigned)a.Hs) rsel |= (a.rowmask >> (9 * j)) & 0x1FFu;
+        if ((unsigned)(ws + j - 1) < (unsigned)a.Ws) csel |= (a.colmask >> (9 * j)) & 0x1FFu;
+      }
+      vm = rsel & csel;
+    }
+    row_dst[tid] = off;
+    row_src[tid] = make_uint2(xo, vm);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Gather-GEMM: LDS-DMA (global_load_lds) staging into an NST-deep LDS ring with counted vmcnt and one raw
 // s_barrier per K-step - the loads of NST-1 stages stay in flight across barriers, which hides the L2/HBM
@@ -115,6 +147,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   long long* row_dst = (long long*)(smem + AUX);
   float* colred = (float*)(smem + AUX + BMP * 8);
+  uint2* row_src = (uint2*)(smem + AUX + BMP * 8 + 1024);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -126,18 +159,8 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
   const int co0 = tc * BNC;
   const int pix0 = tp * BMP;
 
-  if (tid < BMP) {
-    int m = pix0 + tid;
-    long long off = -1;
-    if (m < a.M) {
-      int hw = a.Hg * a.Wg;
-      int n = m / hw, rem = m - n * hw;
-      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
-      int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
-      off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
-    }
-    row_dst[tid] = off;
-  }
+  make_row_tables(a, pix0, tid, BMP, row_dst, row_src);
+  __syncthreads();
 
   // bf16 epilogue operands that live in HBM (residual-gradient addend, y of the fused BN-backward reduction) are
   // fetched here, before the K-loop, so their latency hides under the main loop instead of being paid eight times
@@ -188,20 +211,9 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
   unsigned vmask[XCH];
 #pragma unroll
   for (int i = 0; i < XCH; ++i) {
-    int m = pix0 + rlo + RPR * i;
-    xoff[i] = 0;
-    vmask[i] = 0;
-    if (m < a.M) {
-      int hw = a.Hg * a.Wg;
-      int n = m / hw, rem = m - n * hw;
-      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
-      int hs = ig * a.in_stride, ws = jg * a.in_stride;
-      xoff[i] = (unsigned)(((((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci) * 2);
-      for (int t = 0; t < a.ntaps; ++t) {
-        int dh = (int)((a.tapcode >> (4 * t)) & 3) - 1, dw = (int)((a.tapcode >> (4 * t + 2)) & 3) - 1;
-        if ((unsigned)(hs + dh) < (unsigned)a.Hs && (unsigned)(ws + dw) < (unsigned)a.Ws) vmask[i] |= 1u << t;
-      }
-    }
+    const uint2 rs = row_src[rlo + RPR * i];
+    xoff[i] = rs.x;
+    vmask[i] = rs.y;
   }
   int tap = (kc * 8) / a.Ci;
   int cch = (kc * 8) - tap * a.Ci;
@@ -744,6 +756,7 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   long long* row_dst = (long long*)(smem + AUX);
+  uint2* row_src = (uint2*)(smem + AUX + BMP * 8);
 
   const int tid = threadIdx.x;
   const bool loader = tid < 256;
@@ -754,18 +767,7 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
   const int pix0 = tp * BMP;
   const int nk = a.K_pad / BK;
 
-  if (tid < BMP) {
-    int m = pix0 + tid;
-    long long off = -1;
-    if (m < a.M) {
-      int hw = a.Hg * a.Wg;
-      int n = m / hw, rem = m - n * hw;
-      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
-      int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
-      off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
-    }
-    row_dst[tid] = off;
-  }
+  make_row_tables(a, pix0, tid, BMP, row_dst, row_src);
   __syncthreads();
 
   if (loader) {
@@ -775,20 +777,9 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
     unsigned xoff[XCH], vmask[XCH];
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
-      int m = pix0 + rlo + 32 * i;
-      xoff[i] = 0;
-      vmask[i] = 0;
-      if (m < a.M) {
-        int hw = a.Hg * a.Wg;
-        int n = m / hw, rem = m - n * hw;
-        int ig = rem / a.Wg, jg = rem - ig * a.Wg;
-        int hs = ig * a.in_stride, ws = jg * a.in_stride;
-        xoff[i] = (unsigned)(((((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci) * 2);
-        for (int t = 0; t < a.ntaps; ++t) {
-          int dh = (int)((a.tapcode >> (4 * t)) & 3) - 1, dw = (int)((a.tapcode >> (4 * t + 2)) & 3) - 1;
-          if ((unsigned)(hs + dh) < (unsigned)a.Hs && (unsigned)(ws + dw) < (unsigned)a.Ws) vmask[i] |= 1u << t;
-        }
-      }
+      const uint2 rs = row_src[rlo + 32 * i];
+      xoff[i] = rs.x;
+      vmask[i] = rs.y;
     }
     int tap = (kc * 8) / a.Ci;
     int cch = (kc * 8) - tap * a.Ci;
@@ -892,6 +883,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   using Epi = GemmEpilogue<WC, WP, MT, NT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   long long* row_dst = (long long*)(smem + a.aux);   // behind max(ring, epilogue tile): the fp32 tile of the heads is larger
+  uint2* row_src = (uint2*)(smem + a.aux + BMP * 8);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -908,18 +900,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   const int nk = (ABL && (a.dbg & 2048)) ? 0 : min(nk_all, ks_lo + kper);   // 2048: prologue + epilogue, no K-loop
   if (a.splitk > 1) a.dst = (void*)((float*)a.dst + (long long)krange * a.slab_elems);
 
-  if (tid < BMP) {
-    int m = pix0 + tid;
-    long long off = -1;
-    if (m < a.M) {
-      int hw = a.Hg * a.Wg;
-      int n = m / hw, rem = m - n * hw;
-      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
-      int hd = ig * a.out_stride + a.out_off_h, wd = jg * a.out_stride + a.out_off_w;
-      off = (((long long)n * a.Hd + hd) * a.Wd + wd) * a.Co;
-    }
-    row_dst[tid] = off;
-  }
+  make_row_tables(a, pix0, tid, BMP, row_dst, row_src);
+  __syncthreads();
   Epi epi;                                           // its HBM operands are fetched late (run<.., LATE>): fetched here they
   //                                                    cost 52 bytes of scratch under the 256-register cap of two waves per SIMD
 
@@ -929,19 +911,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   unsigned xoff[XCH], vmask[XCH];
 #pragma unroll
   for (int i = 0; i < XCH; ++i) {
-    int m = pix0 + rlo + RPR * i;
-    xoff[i] = 0; vmask[i] = 0;
-    if (m < a.M) {
-      int hw = a.Hg * a.Wg;
-      int n = m / hw, rem = m - n * hw;
-      int ig = rem / a.Wg, jg = rem - ig * a.Wg;
-      int hs = ig * a.in_stride, ws = jg * a.in_stride;
-      xoff[i] = (unsigned)(((((long long)n * a.Hs + hs) * a.Ws + ws) * a.Ci) * 2);
-      for (int t = 0; t < a.ntaps; ++t) {
-        int dh = (int)((a.tapcode >> (4 * t)) & 3) - 1, dw = (int)((a.tapcode >> (4 * t + 2)) & 3) - 1;
-        if ((unsigned)(hs + dh) < (unsigned)a.Hs && (unsigned)(ws + dw) < (unsigned)a.Ws) vmask[i] |= 1u << t;
-      }
-    }
+    const uint2 rs = row_src[rlo + RPR * i];
+    xoff[i] = rs.x;
+    vmask[i] = rs.y;
   }
   int tap = (kc * 8 + ks_lo * BK) / a.Ci;
   int cch = (kc * 8 + ks_lo * BK) - tap * a.Ci;
@@ -1082,7 +1054,7 @@ int launch_gemm8(GemmArgs& a, hipStream_t st) {
   size_t epi = a.dst_f32 ? (size_t)128 * (128 * 4 + 16) : (size_t)128 * (128 * 2 + 16) + 4 * 2 * 128 * 4;
   const int grid8 = a.nblk * (a.splitk > 1 ? a.splitk : 1);
   a.aux = (int)(ring > epi ? ring : epi);
-  size_t lds = (size_t)a.aux + 128 * 8 + 64;
+  size_t lds = (size_t)a.aux + 128 * 16 + 64;
   auto k = conv_gemm8_kernel<NST, WPE, false, WC>;
   static bool attr = false;
   if (!attr) {
@@ -3392,7 +3364,7 @@ int launch_gemm2(GemmArgs& a, hipStream_t st) {
   a.nblk = a.tilesC * tilesP;
   size_t ring = (size_t)NST * (BNC + BMP) * ROWB;
   size_t epi = (size_t)BMP * (BNC * 4 + 16);       // must match AUX in the kernel
-  ring = (ring > epi ? ring : epi) + (size_t)BMP * 8 + 1024;
+  ring = (ring > epi ? ring : epi) + (size_t)BMP * 16 + 1024;
   auto k = conv_gemm2_kernel<WC, WP, MT, NT, NST>;
   static bool attr = false;
   if (!attr) {
@@ -3411,7 +3383,7 @@ int launch_gemm6(GemmArgs& a, hipStream_t st) {
   a.nblk = a.tilesC * cdiv(a.M, BMP);
   size_t ring = (size_t)NS * (BNC + BMP) * ROWB;
   size_t epi = (size_t)BMP * (BNC * 4 + 16);
-  size_t lds = (ring > epi ? ring : epi) + (size_t)BMP * 8 + 64;
+  size_t lds = (ring > epi ? ring : epi) + (size_t)BMP * 16 + 64;
   auto k = conv_gemm6_kernel<WC, WP, MT, NT, NS>;
   static bool attr = false;
   if (!attr) {
@@ -3555,6 +3527,12 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   MGD_REQUIRE(ok, "conv: tap offsets must lie in [-1,1]");
   a.K_pad = d->K_pad; a.Co_pad = d->Co_pad; a.dst_f32 = d->dst_f32; a.stats_replicas = d->stats_replicas;
   a.M = d->N * d->Hg * d->Wg;
+  a.rowmask = a.colmask = 0;                      // taps by row / column offset: the row tables' validity masks
+  for (int t = 0; t < d->ntaps; ++t) {
+    a.rowmask |= 1u << (9 * (d->dh[t] + 1) + t);
+    a.colmask |= 1u << (9 * (d->dw[t] + 1) + t);
+  }
+  a.splitk = 0; a.slab_elems = 0;
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("MGD_DBG"); dbg = e ? atoi(e) : 0; }
   a.dbg = dbg;
