@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmgd_hip.so")
+# MGD_LIB_AB: A/B measurements of two builds of the library in one GPU call (tools/ab_lib.sh); never set in product runs
+LIB_PATH = os.environ.get("MGD_LIB_AB") or os.path.join(_HERE, "csrc", "libmgd_hip.so")
 _lib = None
 
 

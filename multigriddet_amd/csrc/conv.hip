@@ -130,6 +130,36 @@ __device__ __forceinline__ void wait_vmcnt_tracked() {
   __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
+// XCH pixel pieces of one stage: piece i goes to LDS byte address lds_dst + i * STRIDE (wave-uniform; lane l lands at + 16 l).
+// M0 is the compiler's: saved, set and restored inside ONE statement.
+#define MGD_DMA_FIRST "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %2, 0 offen lds\n\t"
+#define MGD_DMA_NEXT(k) "s_add_u32 m0, m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %" #k ", %2, 0 offen lds\n\t"
+#define MGD_DMA_LAST "s_mov_b32 m0, %0"
+template <int XCH, int STRIDE>
+__device__ __forceinline__ void dma_rows_asm(const unsigned (&v)[XCH], i32x4 srd, unsigned lds_dst) {
+  unsigned keep;
+  static_assert(XCH >= 1 && XCH <= 6, "pixel pieces per wave and stage");
+  if constexpr (XCH == 1)
+    asm volatile(MGD_DMA_FIRST MGD_DMA_LAST : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]) : "memory", "scc");
+  else if constexpr (XCH == 2)
+    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_LAST
+                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]) : "memory", "scc");
+  else if constexpr (XCH == 3)
+    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_NEXT(6) MGD_DMA_LAST
+                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]), "v"(v[2]) : "memory", "scc");
+  else if constexpr (XCH == 4)
+    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_NEXT(6) MGD_DMA_NEXT(7) MGD_DMA_LAST
+                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory", "scc");
+  else if constexpr (XCH == 5)
+    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_NEXT(6) MGD_DMA_NEXT(7) MGD_DMA_NEXT(8) MGD_DMA_LAST
+                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4])
+                 : "memory", "scc");
+  else
+    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_NEXT(6) MGD_DMA_NEXT(7) MGD_DMA_NEXT(8) MGD_DMA_NEXT(9) MGD_DMA_LAST
+                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5])
+                 : "memory", "scc");
+}
+
 template <int WC, int WP, int MT, int NT, int NST>
 __global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
   constexpr int BNC = WC * MT * 16;
@@ -875,7 +905,8 @@ __global__ __launch_bounds__(512) void conv_gemm6_kernel(GemmArgs a) {
 // form with both operands in the ring (conv_gemm2_kernel<2,2,4,4,2>, since removed), 608x608 batch 16: 128->256 at 76x76
 // 79 -> 68 us, 256->512 at 38x38 74 -> 64 us, 64->128 at 152x152 103 -> 85 us; a deeper ring (NST = 3, 4) is not faster.
 // Tile 128 x 128, 4 waves of 32 channels x 128 pixels (WC = 4) or 64 x 64 (WC = 2), epilogue = GemmEpilogue.
-template <int NST, int WPE, bool ABL = false, int WC = 2>   // ABL: ablation build (MGD_DBG bits switch parts of the loop off); WC: waves along the channels
+template <int NST, int WPE, bool ABL = false, int WC = 2, bool UNI = false>   // ABL: ablation build (MGD_DBG bits switch parts of the loop off); WC: waves along the channels;
+//                                                                             UNI: (tap, channel) of a K-step is wave-uniform (ntaps == 1 or Ci % 64 == 0)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void conv_gemm8_kernel(GemmArgs a) {
   constexpr int WP = 4 / WC, MT = 8 / WC, NT = 8 / WP, BNC = 128, BMP = 128, NTHR = 256;
   constexpr int RPR = NTHR / 8, XCH = BMP / RPR;          // 32 rows per LDS-DMA round, 4 pixel pieces per wave and stage
@@ -924,18 +955,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   const char* xbase = (const char*)a.src;
   const void* zero = (const void*)g_zero_page;
   asm volatile("" : "+s"(zero));
-  auto issue = [&](int buf) {                          // stages go out in order
-    unsigned char* xb = smem + buf * STAGE + wave * 1024;
-    const int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
-    const int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
-    const int toff = ((dh * a.Ws + dw) * a.Ci + cch) * 2;
+  // UNI (round 3): tap and first channel of a K-step are the same for every lane, so they live in SGPRs, the pixel rows go
+  // out as buffer_load ... lds through a raw descriptor over the activation tensor (a lane whose tap leaves the image, or
+  // whose K index is padding, presents an out-of-range offset and the hardware writes zeros): per LDS-DMA a mask test, a
+  // 32-bit select and an add instead of a shift, a 64-bit select and a 64-bit add - 40 -> 20 vector instructions per K-step
+  i32x4 srd = {0, 0, 0, 0};
+  int s_tap = 0, s_c0 = 0, s_toff = 0, s_k0 = ks_lo * BK;
+  auto tap_off = [&](int tp_) {
+    const int dh = (int)((a.tapcode >> (4 * tp_)) & 3) - 1;
+    const int dw = (int)((a.tapcode >> (4 * tp_ + 2)) & 3) - 1;
+    return (dh * a.Ws + dw) * a.Ci * 2;
+  };
+  if (UNI) {
+    const unsigned long long p = (unsigned long long)a.src;
+    srd[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+    srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    srd[2] = __builtin_amdgcn_readfirstlane((unsigned)((long long)a.N * a.Hs * a.Ws * a.Ci * 2));
+    srd[3] = 0x00020000;
+    s_tap = (ks_lo * BK) / a.Ci;
+    s_c0 = ks_lo * BK - s_tap * a.Ci;
+    s_toff = tap_off(s_tap) + s_c0 * 2;
 #pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-      const bool v = (vmask[i] >> tap) & 1u;
-      glds16(v ? (const void*)(xbase + (xoff[i] + (unsigned)toff)) : zero, xb + i * (RPR * ROWB));
+    for (int i = 0; i < XCH; ++i) xoff[i] += kc * 16;
+  }
+  const int Kreal = a.ntaps * a.Ci;
+  const unsigned lds_w = lds_addr(smem) + wave * 1024;
+  auto issue = [&](int buf) {                          // stages go out in order
+    if constexpr (UNI) {
+      const unsigned bit = 1u << s_tap;
+      const bool kin = s_k0 + kc * 8 < Kreal;             // K padding of the last step reads as zeros
+      unsigned vo[XCH];
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) vo[i] = ((vmask[i] & bit) && kin) ? xoff[i] + (unsigned)s_toff : 0xFFFFFFF0u;
+      dma_rows_asm<XCH, RPR * ROWB>(vo, srd, lds_w + buf * STAGE);
+      s_k0 += BK;
+      s_c0 += BK;
+      s_toff += BK * 2;
+      if (s_c0 >= a.Ci) { s_c0 -= a.Ci; ++s_tap; s_toff = tap_off(s_tap) + s_c0 * 2; }
+    } else {
+      unsigned char* xb = smem + buf * STAGE + wave * 1024;
+      const int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
+      const int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
+      const int toff = ((dh * a.Ws + dw) * a.Ci + cch) * 2;
+#pragma unroll
+      for (int i = 0; i < XCH; ++i) {
+        const bool v = (vmask[i] >> tap) & 1u;
+        glds16(v ? (const void*)(xbase + (xoff[i] + (unsigned)toff)) : zero, xb + i * (RPR * ROWB));
+      }
+      cch += BK;
+      while (cch >= a.Ci) { cch -= a.Ci; ++tap; }
     }
-    cch += BK;
-    while (cch >= a.Ci) { cch -= a.Ci; ++tap; }
   };
 
   f32x4 acc[MT][NT];
@@ -1046,7 +1115,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
   *(uint4*)(dst + e) = pack8(v);
 }
 
-template <int NST, int WPE, int WC = 2>
+template <int NST, int WPE, int WC = 2, bool UNI = false>
 int launch_gemm8(GemmArgs& a, hipStream_t st) {
   a.tilesC = a.Co_pad / 128;
   a.nblk = a.tilesC * cdiv(a.M, 128);
@@ -1055,7 +1124,7 @@ int launch_gemm8(GemmArgs& a, hipStream_t st) {
   const int grid8 = a.nblk * (a.splitk > 1 ? a.splitk : 1);
   a.aux = (int)(ring > epi ? ring : epi);
   size_t lds = (size_t)a.aux + 128 * 16 + 64;
-  auto k = conv_gemm8_kernel<NST, WPE, false, WC>;
+  auto k = conv_gemm8_kernel<NST, WPE, false, WC, UNI>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1091,36 +1160,6 @@ __device__ __forceinline__ int sgpr(int v) {
 // Tile 128 channels x 16*NT pixels (NT = 8, 6, 4: the host picks the pixel tile that fills the 512 block slots best),
 // 4 waves of 32 channels x 16*NT pixels, NST-deep ring of pixel stages, NST register sets of weight fragments, 2 blocks
 // per CU (<= 256 registers).  Persistent: the grid is min(tiles, 512) and a block walks tiles blockIdx.x + i * gridDim.x.
-// XCH pixel pieces of one stage: piece i goes to LDS byte address lds_dst + i * STRIDE (wave-uniform; lane l lands at + 16 l).
-// M0 is the compiler's: saved, set and restored inside ONE statement.
-#define MGD_DMA_FIRST "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %2, 0 offen lds\n\t"
-#define MGD_DMA_NEXT(k) "s_add_u32 m0, m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %" #k ", %2, 0 offen lds\n\t"
-#define MGD_DMA_LAST "s_mov_b32 m0, %0"
-template <int XCH, int STRIDE>
-__device__ __forceinline__ void dma_rows_asm(const unsigned (&v)[XCH], i32x4 srd, unsigned lds_dst) {
-  unsigned keep;
-  static_assert(XCH >= 1 && XCH <= 6, "pixel pieces per wave and stage");
-  if constexpr (XCH == 1)
-    asm volatile(MGD_DMA_FIRST MGD_DMA_LAST : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]) : "memory", "scc");
-  else if constexpr (XCH == 2)
-    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_LAST
-                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]) : "memory", "scc");
-  else if constexpr (XCH == 3)
-    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_NEXT(6) MGD_DMA_LAST
-                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]), "v"(v[2]) : "memory", "scc");
-  else if constexpr (XCH == 4)
-    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_NEXT(6) MGD_DMA_NEXT(7) MGD_DMA_LAST
-                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory", "scc");
-  else if constexpr (XCH == 5)
-    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_NEXT(6) MGD_DMA_NEXT(7) MGD_DMA_NEXT(8) MGD_DMA_LAST
-                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4])
-                 : "memory", "scc");
-  else
-    asm volatile(MGD_DMA_FIRST MGD_DMA_NEXT(5) MGD_DMA_NEXT(6) MGD_DMA_NEXT(7) MGD_DMA_NEXT(8) MGD_DMA_NEXT(9) MGD_DMA_LAST
-                 : "=&s"(keep) : "s"(lds_dst), "s"(srd), "n"(STRIDE), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5])
-                 : "memory", "scc");
-}
-
 // the four weight fragments of a K-step (2 channel groups x 2 k-halves), 1 KiB apart in the fragment-ordered image
 // (s_nop 4: the base may come straight from v_readfirstlane - a VALU write of an SGPR needs five wait states before a
 // vector-memory instruction reads it as an address, and hipcc pads nothing inside an asm statement; without it the loads of
@@ -3591,7 +3630,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
       GemmArgs p = a;
       p.splitk = d->splitk; p.slab_elems = slab;
       p.dst = d->partial; p.dst_f32 = 1; p.bias = nullptr; p.addend = nullptr; p.act_slope = 0.f;
-      launch_gemm8<2, 3, 4>(p, st);
+      if (d->ntaps == 1 || d->Ci % 64 == 0) launch_gemm8<2, 3, 4, true>(p, st); else launch_gemm8<2, 3, 4>(p, st);
       MGD_CHECK_LAUNCH("conv_gather_gemm(split-K)");
       const long long total8 = slab / 8;
       hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)cdiv(total8, 256)), dim3(256), 0, st, (const float*)d->partial,
@@ -3728,7 +3767,11 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     // waves of 64 x 64 the two waves of a channel row fetch the same fragments, 48 KB instead of 32 KB per K-step through the
     // CU's vector-memory path (64 B/clk): forward convs 2.91 -> 2.78 ms
     if (g8wc < 0) { const char* e = getenv("MGD_GEMM8_WC"); g8wc = e ? atoi(e) : 4; }
-    if (g8wc == 4) launch_gemm8<2, 3, 4>(a, st); else launch_gemm8<2, 3, 2>(a, st);
+    static int g8uni = -1;
+    if (g8uni < 0) { const char* e = getenv("MGD_GEMM8_UNI"); g8uni = e ? atoi(e) : 1; }
+    const bool uni = g8uni && (d->ntaps == 1 || d->Ci % 64 == 0) && !(a.dbg & 0xFE1);
+    if (g8wc == 4) { if (uni) launch_gemm8<2, 3, 4, true>(a, st); else launch_gemm8<2, 3, 4>(a, st); }
+    else launch_gemm8<2, 3, 2>(a, st);
     MGD_CHECK_LAUNCH("conv_gather_gemm(global weight fragments)");
     return MGD_OK;
   }
