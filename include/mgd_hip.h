@@ -99,9 +99,26 @@ typedef struct mgd_conv_desc {
   int32_t splitk;
   float* partial;
   int64_t partial_bytes;
+  /* Latency form (latency != 0) for launches of a few thousand pixels (small-batch inference: 75 dependent launches, each
+   * far too small to fill 256 CUs with 128 x 128 tiles): blocks of 128 channels x 64 pixels x one of max(splitk, 1) K
+   * ranges, all of a block's K-steps in flight at once, and the ranges added INSIDE the kernel by the last block to arrive
+   * at each tile (in range order: deterministic) - no second launch.  With splitk > 1 `partial` is the workspace: 16 KiB of
+   * tile tickets that the caller zero-fills ONCE (launches leave them at zero), then splitk * tiles * 32 KiB of fp32
+   * partial tiles, tiles = Co_pad/128 * ceil(N*Hg*Wg / 64) <= 4096; partial_bytes covers both.  Launches that share a
+   * workspace must be ordered on one stream.  Needs Co_pad % 128 == 0, bf16 output, no stats / bn_y, and ntaps == 1 or
+   * Ci % 64 == 0; anything else is refused. */
+  int32_t latency;
 } mgd_conv_desc;
 
 int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream);
+
+/* Workspace for mgd_conv_desc.latency with splitk > 1: uncached device memory owned by the library (one buffer per device,
+ * grown on demand, the ticket area zero-filled) - partial tiles written by blocks on one XCD are read by a block on another
+ * inside the same kernel, which ordinary (L2-cached) device memory does not guarantee.  *out / *capacity: the buffer and its
+ * size (>= bytes).  Synchronises the device when it has to (re)allocate: call it once with the largest size before capturing
+ * a stream.  mgd_latency_tickets: test hook, copies the 4096 tickets to the host. */
+int mgd_latency_workspace(int64_t bytes, void** out, int64_t* capacity);
+int mgd_latency_tickets(unsigned* out4096);
 
 
 /* Stride-2 data gradient of a 3x3 conv with 32 input / 64 output channels (the first down-sampling layer,

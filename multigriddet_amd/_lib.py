@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
         ("K_pad", C.c_int32), ("Co_pad", C.c_int32), ("dst_f32", C.c_int32), ("stats_replicas", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_mean", C.c_void_p),
         ("bn_invstd", C.c_void_p), ("bn_sums", C.c_void_p), ("bn_slope", C.c_float), ("act_slope", C.c_float),
-        ("splitk", C.c_int32), ("partial", C.c_void_p), ("partial_bytes", C.c_int64),
+        ("splitk", C.c_int32), ("partial", C.c_void_p), ("partial_bytes", C.c_int64), ("latency", C.c_int32),
     ]
 
 
@@ -103,7 +103,7 @@ class DecodeCfg(C.Structure):
 
 # every symbol include/mgd_hip.h declares
 EXPORTS = [
-    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_debug_stamps", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_stem_fwd", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
+    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_debug_stamps", "mgd_latency_workspace", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_stem_fwd", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
     "mgd_pack_weights", "mgd_pack_weights_batch", "mgd_stem_im2col", "mgd_bn_finalize", "mgd_bn_act_fwd", "mgd_bn_act_fwd_fused", "mgd_bn_act_bwd_reduce", "mgd_bn_act_bwd_apply",
     "mgd_upsample_concat_fwd", "mgd_upsample_concat_bwd", "mgd_bias_grad", "mgd_f32_to_bf16", "mgd_bf16_to_f32",
     "mgd_adam_step", "mgd_adam_step_dev", "mgd_sgd_step", "mgd_build_targets_workspace_size", "mgd_build_targets",

@@ -47,6 +47,8 @@ struct GemmArgs {
   unsigned rowmask, colmask;   // conv_gemm9_kernel: 3 x 9 bits, the taps with dh + 1 == j / dw + 1 == j (bits 9j .. 9j+8)
   int splitk;                  // conv_gemm8_kernel: K ranges per tile (blocks = nblk * splitk); fp32 partial tiles go to
   long long slab_elems;        //   (float*)dst + range * slab_elems
+  float* partial;              // conv_gemm11_kernel: fp32 partial tiles [range][tile][128 x 64 in fragment order]
+  unsigned* tickets;           //   and one arrival counter per tile (zero between launches)
 };
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * ROWB + ((kc ^ (row & 7)) << 4); }
@@ -1850,6 +1852,233 @@ int launch_gemm10(GemmArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Latency form of the gather-GEMM (round 3): small-batch inference.  At batch 1 a 608 x 608 forward is 75 DEPENDENT launches
+// of 5 - 6 000 pixels each; the kernel trace (tools/trace_timeline.py) shows no idle gaps - the time is the kernels' own:
+// 8 - 42 us each for 0.4 - 3.4 GFLOP.  Such a launch has 12 - 90 tiles of 128 x 128 for 256 CUs, and each block walks its
+// whole K-loop (up to 72 steps) with one or two stages in flight: a step costs a memory round trip (the weights are touched
+// once per forward: they come from HBM / the memory-side cache, 1 - 2 us away) and a CU pulls its tile's share of the
+// weights alone - 512 -> 1024 at 19 x 19 streams 9.4 MB through 24 CUs.  What the layer needs is the opposite shape:
+//  * every CU pulls weights: K is cut into `splitk` ranges, (tile, range) blocks of 128 channels x 64 pixels - a few
+//    hundred blocks of 2 - 12 K-steps;
+//  * everything a block will read is in flight at once: weights AND pixel rows come by LDS-DMA into an NST-deep ring (24
+//    KiB a stage), so all of a wave's vector-memory operations are of one kind and retire in order - the counted wait
+//    s_waitcnt vmcnt((NST - 2) * 6) is exact (with weight fragments loaded to registers the two kinds overtake each other and
+//    the count has to assume the worst, see conv_gemm9_kernel) - and nothing in flight lives in a register, so the loop needs
+//    no static register sets: a plain loop over the block's steps, dummy stages (all lanes out of range: no traffic, same
+//    count) behind the last one.  A wave reads back only the weight fragments it fetched itself;
+//  * the ranges meet in the kernel, not in a second launch: a block stores its fp32 partial tile in fragment order (16
+//    bytes per lane, coalesced), takes a ticket of its tile (fence, atomic), and the block that draws the last ticket adds all
+//    ranges IN RANGE ORDER (deterministic, whoever comes last), applies bias / LeakyReLU / residual and writes bf16.  Tickets
+//    are left at zero for the next launch.
+// bf16 output without BatchNorm statistics / fused reductions; (tap, channel) of a K-step wave-uniform (ntaps == 1 or
+// Ci % 64 == 0).  One block per CU (the ring is 144 KiB).
+template <int NT, int NST>
+__global__ __launch_bounds__(256) void conv_gemm11_kernel(GemmArgs a) {
+  constexpr int WC = 4, WP = 1, MT = 2, BNC = 128, BMP = 16 * NT, NTHR = 256;
+  constexpr int RPR = NTHR / 8, XCH = BMP / RPR;             // 32 rows per DMA round; pixel pieces per wave and stage
+  constexpr int PIXB = BMP * ROWB, STAGE = PIXB + 4 * 4096;  // pixel rows, then each wave's four weight fragments
+  constexpr int GRP = 4 + XCH, DIST = NST - 1, WS = (DIST - 1) * GRP;
+  static_assert(BMP % RPR == 0 && NST >= 2 && WS <= 63, "ring");
+  using Epi = GemmEpilogue<WC, WP, MT, NT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  long long* row_dst = (long long*)(smem + a.aux);
+  uint2* row_src = (uint2*)(smem + a.aux + BMP * 8);
+  int* last_flag = (int*)(smem + a.aux + BMP * 16);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = a.K_pad / BK;
+  const int Kreal = a.ntaps * a.Ci;
+  const int S = a.splitk > 1 ? a.splitk : 1;
+  const int tilesP = a.nblk / a.tilesC;
+  // blocks that share weights (same channel tile and K range, consecutive pixel tiles) sit on one XCD
+  const int L = xcd_remap(blockIdx.x, a.nblk * S);
+  const int tp = L % tilesP, rest = L / tilesP;
+  const int tc = rest % a.tilesC, split = rest / a.tilesC;
+  const int tile = tc * tilesP + tp;
+  const int co0 = tc * BNC, pix0 = tp * BMP;
+  const int kbase = nk / S, kextra = nk - kbase * S;
+  const int k0 = split * kbase + min(split, kextra);
+  const int nkb = kbase + (split < kextra ? 1 : 0);           // >= 1 (host: S <= nk)
+
+  auto make_srd = [&](const void* ptr, long long bytes) {
+    const unsigned long long p = (unsigned long long)ptr;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    r[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes);
+    r[3] = 0x00020000;
+    return r;
+  };
+  const i32x4 srd = make_srd(a.src, (long long)a.N * a.Hs * a.Ws * a.Ci * 2);
+  const i32x4 wsrd = make_srd(a.wpk, (long long)a.Co_pad * a.K_pad * 2);
+  const unsigned OOB = 0xFFFFFFF0u;
+
+  make_row_tables(a, pix0, tid, BMP, row_dst, row_src);
+  lds_barrier();
+  const int rlo = tid >> 3;
+  const int kc = (tid & 7) ^ (rlo & 7);
+  unsigned xoff[XCH], vmask[XCH];
+#pragma unroll
+  for (int i = 0; i < XCH; ++i) {
+    const uint2 rs = row_src[rlo + RPR * i];
+    xoff[i] = rs.x + kc * 16;
+    vmask[i] = rs.y;
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  int xro[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) xro[n] = lds_off(n * 16 + fr, fq);
+
+  // wave-uniform K-step state, starting at the block's first step
+  auto tap_off = [&](int tp_) {
+    const int dh = (int)((a.tapcode >> (4 * tp_)) & 3) - 1;
+    const int dw = (int)((a.tapcode >> (4 * tp_ + 2)) & 3) - 1;
+    return (dh * a.Ws + dw) * a.Ci * 2;
+  };
+  int s_k0 = k0 * BK, s_tap = 0, s_c0 = s_k0;
+  if (a.ntaps > 1) { s_tap = s_k0 / a.Ci; s_c0 = s_k0 - s_tap * a.Ci; }
+  int s_toff = tap_off(s_tap) + s_c0 * 2;
+  int s_issued = 0;
+  const unsigned ldsp = lds_addr(smem) + wave * 1024;
+  const unsigned ldsw = lds_addr(smem) + PIXB + wave * 4096;
+  // this wave's four fragments of (channel tile tc, K-step k0): 1 KiB each, lane l's 16 bytes at + 16 l
+  const unsigned wlane = (unsigned)((((size_t)tc * nk + k0) * 16 + (size_t)wave * 4) * 1024) + lane * 16;
+  auto issue = [&](int buf) {
+    const bool real = s_issued < nkb;
+    const unsigned bit = 1u << s_tap;
+    const bool kin = real && (s_k0 + kc * 8 < Kreal);         // K padding of the last step reads as zeros
+    unsigned vo[XCH], wv[4];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) vo[i] = ((vmask[i] & bit) && kin) ? xoff[i] + (unsigned)s_toff : OOB;
+    const unsigned wo = wlane + (unsigned)s_issued * 16384u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wv[i] = real ? wo + i * 1024 : OOB;
+    dma_rows_asm<4, 1024>(wv, wsrd, ldsw + buf * STAGE);
+    dma_rows_asm<XCH, RPR * ROWB>(vo, srd, ldsp + buf * STAGE);
+    ++s_issued;
+    if (real) {
+      s_k0 += BK;
+      s_c0 += BK;
+      s_toff += BK * 2;
+      if (s_c0 >= a.Ci) { s_c0 -= a.Ci; ++s_tap; s_toff = tap_off(s_tap) + s_c0 * 2; }
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int st = 0; st < DIST; ++st) issue(st);
+  int buf = 0, nbuf = DIST;
+  for (int s = 0; s < nkb; ++s) {
+    wait_vmcnt<WS>();                                          // stage s has landed (this wave's pieces; the barrier: everyone's)
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* sb = smem + buf * STAGE;
+    const unsigned char* wb = sb + PIXB + wave * 4096 + lane * 16;
+    bf16x8 xf[NT], wf[MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + xro[n]);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(wb + m * 2048);
+    issue(nbuf);                                               // into the slot everyone left before this barrier
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (kk) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) xf[n] = *(const bf16x8*)(sb + (xro[n] ^ 64));
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wf[m] = *(const bf16x8*)(wb + m * 2048 + 1024);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf[n], acc[m][n], 0, 0, 0);
+    }
+    buf = buf + 1 == NST ? 0 : buf + 1;
+    nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+  }
+  // the dummy stages still in flight write zeros into the ring: they must have landed before the epilogue reuses it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_nop 7" ::: "memory");
+  lds_barrier();
+
+  if (S > 1) {
+    // Partial tiles cross XCDs (each has its own L2, not coherent with the others for ordinary device memory inside a
+    // kernel): the workspace is UNCACHED device memory (mgd_latency_workspace) and is stored / loaded at system scope, ordered
+    // by the stores' completion, the block barrier and the ticket atomic.  (Release / acquire FENCES make ordinary memory work
+    // too - buffer_wbl2 + buffer_inv of the whole L2 per block: measured 80 - 100 us a launch; scope bits alone on ordinary
+    // memory did not: ranges were read stale.)
+    constexpr int TILE_F4 = BNC * BMP / 4;                     // f32x4 elements per partial tile
+    f32x4* mine = (f32x4*)a.partial + ((size_t)split * a.nblk + tile) * TILE_F4 + tid;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        // (s_nop 1: a store of more than 64 bits reads its data registers for two more wait states; hipcc pads that for
+        // its own stores but not behind an asm statement, and re-filled v[4:7] from the accumulators right behind each store)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + (m * NT + n) * NTHR), "v"(acc[m][n]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // written through before the ticket
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned t = atomicAdd(a.tickets + tile, 1u);
+      *last_flag = t == (unsigned)(S - 1);
+    }
+    __syncthreads();
+    if (!*last_flag) return;
+    const f32x4* all = (const f32x4*)a.partial + (size_t)tile * TILE_F4 + tid;
+    const size_t rstride = (size_t)a.nblk * TILE_F4;
+    // in range order (the sum does not depend on who came last); four whole ranges (32 loads a lane) in flight at a time:
+    // every round is a full trip to memory, and the chain store -> ticket -> loads is what K ranges cost (~6 us)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < S; r0 += 4) {
+      f32x4 v[4][MT * NT];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4* pr = all + (size_t)min(r0 + r, S - 1) * rstride;
+#pragma unroll
+        for (int q = 0; q < MT * NT; ++q) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v[r][q]) : "v"(pr + q * NTHR) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int q = 0; q < MT * NT; ++q) {
+          asm volatile("" : "+v"(v[r][q]));                    // consumers stay behind the wait
+          if (r0 + r < S) acc[q / NT][q % NT] += v[r][q];
+        }
+      }
+    }
+    if (tid == 0) a.tickets[tile] = 0u;
+  }
+  Epi epi;
+  epi.template run_grouped<Epi::EPC>(a, acc, smem, row_dst, co0, tid);
+}
+
+template <int NT, int NST>
+int launch_gemm11(GemmArgs& a, hipStream_t st) {
+  constexpr int BMP = 16 * NT, STAGE = BMP * ROWB + 4 * 4096;
+  size_t ring = (size_t)NST * STAGE;
+  size_t epi = (size_t)BMP * (128 * 2 + 16) + (size_t)4 * 2 * 128 * 4;
+  a.aux = (int)(ring > epi ? ring : epi);
+  size_t lds = (size_t)a.aux + BMP * 16 + 64;
+  auto k = conv_gemm11_kernel<NT, NST>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(a.nblk * (a.splitk > 1 ? a.splitk : 1)), dim3(256), lds, st, a);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // "Patch" form of the 3x3 gather-GEMM for the thin early layers (CI, CO <= 64: all nine taps of the weights fit in
 // LDS).  The v2 kernel walks K = 9*CI in 64-deep steps and is bound by one LDS-DMA round trip per step (1.63 us), i.e.
 // by nothing the layer itself needs: the input is re-read nine times through L2.  Here a persistent block keeps the
@@ -3571,7 +3800,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
     a.rowmask |= 1u << (9 * (d->dh[t] + 1) + t);
     a.colmask |= 1u << (9 * (d->dw[t] + 1) + t);
   }
-  a.splitk = 0; a.slab_elems = 0;
+  a.splitk = 0; a.slab_elems = 0; a.partial = nullptr; a.tickets = nullptr;
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("MGD_DBG"); dbg = e ? atoi(e) : 0; }
   a.dbg = dbg;
@@ -3617,6 +3846,25 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   //    block per CU hides the latency of a long K-loop better than a third of the CUs' worth of barrier-synchronous blocks
   //    (1024->512 at 19x19, 184 tiles: 66 us against 108);
   //  * everything else: weights straight from global memory, three blocks per CU.
+  if (d->latency) {
+    // latency form (see mgd_conv_desc.latency): deep-ring (tile, K range) blocks, the ranges added inside the kernel
+    MGD_REQUIRE(d->Co_pad % 128 == 0 && !d->dst_f32 && !d->stats && !d->bn_y && (d->ntaps == 1 || d->Ci % 64 == 0),
+                "conv: the latency form needs 128-channel weight tiles, bf16 output without statistics / fused reductions and wave-uniform K-steps (ntaps == 1 or Ci %% 64 == 0)");
+    const int S = d->splitk > 1 ? d->splitk : 1;
+    MGD_REQUIRE(S <= nk, "conv: more K ranges than K-steps");
+    a.tilesC = d->Co_pad / 128;
+    a.nblk = a.tilesC * cdiv(a.M, 64);
+    a.splitk = S; a.partial = nullptr; a.tickets = nullptr;
+    if (S > 1) {
+      MGD_REQUIRE(a.nblk <= 4096, "conv: latency form with K ranges: at most 4096 tiles (got %d)", a.nblk);
+      MGD_REQUIRE(d->partial && d->partial_bytes >= 16384 + (int64_t)S * a.nblk * 128 * 64 * 4, "conv: latency-form workspace too small");
+      a.tickets = (unsigned*)d->partial;
+      a.partial = d->partial + 4096;
+    }
+    launch_gemm11<4, 6>(a, st);
+    MGD_CHECK_LAUNCH("conv_gather_gemm(latency form)");
+    return MGD_OK;
+  }
   if (d->Co_pad % 128 == 0) {
     a.splitk = 0; a.slab_elems = 0;
     if (d->splitk > 1) {
@@ -4005,6 +4253,40 @@ extern "C" int mgd_pack_weights_batch(const mgd_pack_job* jobs_dev, int njobs, i
 }
 
 // Diagnostic: reads and clears the phase stamps of the stamped conv_gemm9_kernel build (MGD_DBG=4096, MGD_GEMM9_PP=4).
+// Workspace of the latency form (mgd_conv_desc.latency with splitk > 1): uncached device memory owned by the library, one
+// buffer per device, grown on demand (the first 16 KiB, the tile tickets, zero-filled).  Not for use during stream capture:
+// call once with the largest size before capturing.
+extern "C" int mgd_latency_workspace(int64_t bytes, void** out, int64_t* capacity) {
+  MGD_REQUIRE(out && bytes >= 16384, "latency_workspace: at least the 16 KiB of tickets");
+  static void* ws[64];
+  static int64_t cap[64];
+  int dev = 0;
+  MGD_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "latency_workspace: device");
+  if (cap[dev] < bytes) {
+    MGD_REQUIRE(hipDeviceSynchronize() == hipSuccess, "latency_workspace: synchronize");
+    if (ws[dev]) (void)hipFree(ws[dev]);
+    ws[dev] = nullptr; cap[dev] = 0;
+    void* p = nullptr;
+    MGD_REQUIRE(hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached) == hipSuccess && p, "latency_workspace: allocation of %lld bytes failed", (long long)bytes);
+    MGD_REQUIRE(hipMemset(p, 0, 16384) == hipSuccess && hipDeviceSynchronize() == hipSuccess, "latency_workspace: memset");
+    ws[dev] = p; cap[dev] = bytes;
+  }
+  *out = ws[dev];
+  if (capacity) *capacity = cap[dev];
+  return MGD_OK;
+}
+
+// test hook: the 4096 tile tickets of the current device's workspace, copied to the host (all zero between launches)
+extern "C" int mgd_latency_tickets(unsigned* out4096) {
+  MGD_REQUIRE(out4096, "latency_tickets: null pointer");
+  void* p = nullptr;
+  int64_t c = 0;
+  int rc = mgd_latency_workspace(16384, &p, &c);
+  if (rc != MGD_OK) return rc;
+  MGD_REQUIRE(hipDeviceSynchronize() == hipSuccess && hipMemcpy(out4096, p, 16384, hipMemcpyDeviceToHost) == hipSuccess, "latency_tickets: copy");
+  return MGD_OK;
+}
+
 extern "C" int mgd_debug_stamps(unsigned long long* out16) {
   MGD_REQUIRE(out16, "debug_stamps: null pointer");
   unsigned long long z[24] = {0};

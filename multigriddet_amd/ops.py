@@ -185,6 +185,15 @@ def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False, act_slope=0.
     dh, dw = taps_fwd(pk.k)
     d = _desc(x, pk.fwd if wimg is None else wimg, out, N, H, W, Ci, Ho, Wo, Ho, Wo, pk.co, pk.s, 1, (0, 0), dh, dw,
               pk.fwd_kpad, pk.fwd_copad, bias=bias, stats=stats, dst_f32=out_f32, act_slope=act_slope, addend=addend)
+    lat = latency_plan(N * Ho * Wo, pk.fwd_copad, pk.fwd_kpad, len(dh), Ci) if (stats is None and not out_f32 and LATENCY) else 0
+    if lat:
+        # a few thousand pixels (small-batch inference): (tile, K range) blocks with everything in flight, ranges added in-kernel
+        d.latency, d.splitk = 1, lat
+        if lat > 1:
+            tiles = (pk.fwd_copad // 128) * -(-(N * Ho * Wo) // 64)
+            d.partial, d.partial_bytes = _latency_workspace(16384 + lat * tiles * 32768, x.device)
+        _launch_gemm(d, "conv_fwd")
+        return out
     sp = splitk_factor(N * Ho * Wo, pk.fwd_copad, pk.fwd_kpad) if (stats is None and not out_f32 and SPLITK) else 1
     if sp > 1:
         # few output tiles, long contraction (small-batch inference on the 19 x 19 / 38 x 38 maps): K ranges on separate CUs
@@ -192,6 +201,40 @@ def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False, act_slope=0.
         d.splitk, d.partial, d.partial_bytes = sp, ws.data_ptr(), ws.numel() * 4
     _launch_gemm(d, "conv_fwd")
     return out
+
+
+# Latency form (mgd_conv_desc.latency; MGD_LATENCY=0 turns it off): launches of at most LAT_TILES tiles of 128 channels x 64
+# pixels - a 608 x 608 forward at batch 1 - 2.  K ranges: as many as bring the launch to about LAT_BLOCKS blocks (one per
+# CU and round) while every block keeps at least two K-steps.
+LATENCY = os.environ.get("MGD_LATENCY", "1") == "1"
+LAT_TILES = int(os.environ.get("MGD_LAT_TILES", "256"))
+LAT_BLOCKS = int(os.environ.get("MGD_LAT_BLOCKS", "256"))
+LAT_RANGES = int(os.environ.get("MGD_LAT_RANGES", "4"))
+LAT_MIN_STEPS = int(os.environ.get("MGD_LAT_MIN_STEPS", "32"))
+_LATENCY_WS = {}
+
+
+def latency_plan(M, co_pad, k_pad, ntaps, ci):
+    """0: regular dispatch; S >= 1: the latency form with S K ranges."""
+    if co_pad % 128 or not (ntaps == 1 or ci % 64 == 0):
+        return 0
+    tiles, nk = (co_pad // 128) * -(-M // 64), k_pad // 64
+    if tiles > LAT_TILES:
+        return 0
+    if nk < LAT_MIN_STEPS:
+        return 1
+    return max(1, min(nk // 4, LAT_RANGES, LAT_BLOCKS // tiles))
+
+
+def _latency_workspace(nbytes, device):
+    """(pointer, capacity) of the library's uncached workspace on the current device: tickets (zero between launches) +
+    partial tiles, shared by the launches of a stream; sized once for 1024 (tile, range) blocks."""
+    ws = _LATENCY_WS.get(device)
+    if ws is None or ws[1] < nbytes:
+        p, cap = C.c_void_p(), C.c_int64()
+        L.check(L.load().mgd_latency_workspace(max(nbytes, 16384 + 1024 * 32768), C.byref(p), C.byref(cap)), "latency_workspace")
+        ws = _LATENCY_WS[device] = (p.value, cap.value)
+    return ws
 
 
 # opt-in (MGD_SPLITK=1): measured at batch 1, 608 x 608 - the 19 x 19 3x3 launches 43 -> 25 us and the 38 x 38 ones 29.5 -> 25 us

@@ -325,8 +325,9 @@ def test_conv_split_k_matches_reference(dev, N, H, W, Ci, Co, k, s, splits):
     res = bf(torch.randn(*y_ref.shape, generator=g))
     ref = torch.where(y_ref > 0, y_ref, 0.1 * y_ref) + res.float()
     xd, bd, rd = x.to(dev), bias.to(dev), res.to(dev)
-    was = ops.SPLITK
+    was, was_lat = ops.SPLITK, ops.LATENCY
     ops.SPLITK = True                                  # opt-in route (MGD_SPLITK=1)
+    ops.LATENCY = False                                # (the default route for shapes this small, tested below)
     try:
         out = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
         assert ops.L.load().mgd_last_kernel() == b"conv_gather_gemm(split-K)"
@@ -334,12 +335,71 @@ def test_conv_split_k_matches_reference(dev, N, H, W, Ci, Co, k, s, splits):
         ops.SPLITK = False
         single = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
     finally:
-        ops.SPLITK = was
+        ops.SPLITK, ops.LATENCY = was, was_lat
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
     tol = 0.02 * ref.abs().max().item() + 1e-3
     assert (out.float().cpu() - ref).abs().max().item() <= tol
     assert (out.float() - single.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co,k,s,cap,ranges", [(1, 19, 19, 512, 1024, 3, 1, 4, 4), (1, 38, 38, 256, 512, 3, 1, 4, 2),
+                                                        (1, 76, 76, 128, 256, 3, 1, 4, 1), (1, 19, 19, 1024, 512, 1, 1, 4, 1),
+                                                        (2, 38, 38, 512, 256, 1, 1, 4, 1), (1, 76, 76, 256, 128, 1, 1, 4, 1),
+                                                        (1, 38, 38, 512, 1024, 3, 2, 4, 4), (1, 13, 11, 256, 384, 3, 1, 4, 4),
+                                                        (1, 76, 76, 64, 128, 3, 1, 4, 1), (3, 9, 7, 128, 128, 1, 1, 4, 1),
+                                                        (1, 19, 19, 512, 1024, 3, 1, 5, 5), (1, 13, 11, 256, 384, 3, 1, 9, 9),
+                                                        (1, 19, 19, 1024, 512, 3, 1, 16, 10)])
+def test_conv_latency_form_matches_reference(dev, N, H, W, Ci, Co, k, s, cap, ranges, monkeypatch):
+    """Latency form of the forward convolution (mgd_conv_desc.latency: launches of a few thousand pixels - the 608 x 608
+    forward at batch 1 - 2): (tile, K range) blocks with every K-step in flight, the ranges added inside the kernel by the
+    last block to reach each tile.  The result equals the fp32 torch reference within the bf16 output rounding and the
+    regular route within one bf16 ulp of the operand scale (summation order); three calls in a row are bit-identical (the
+    ranges are added in range order whoever arrives last, and the tickets are back at zero after every launch)."""
+    from multigriddet_amd import ops
+    g = torch.Generator().manual_seed(4242 + Ci + Co + H)
+    x = bf(torch.randn(N, H, W, Ci, generator=g))
+    w = torch.randn(Co, k * k, Ci, generator=g) / (k * (Ci ** 0.5))
+    bias = torch.randn(Co, generator=g) * 0.5
+    pk = ops.PackedConv(Co, Ci, k, s, dev)
+    pk.refresh(w.to(dev))
+    Ho, Wo = (H // 2, W // 2) if s == 2 else (H, W)
+    monkeypatch.setattr(ops, "LAT_RANGES", cap)        # (the default cap is 4: one round of partial-tile loads)
+    assert ops.LATENCY and ops.latency_plan(N * Ho * Wo, pk.fwd_copad, pk.fwd_kpad, k * k, Ci) == ranges
+    y_ref = _ref_conv(x, w, k, s) + bias
+    res = bf(torch.randn(*y_ref.shape, generator=g))
+    ref = torch.where(y_ref > 0, y_ref, 0.1 * y_ref) + res.float()
+    xd, bd, rd = x.to(dev), bias.to(dev), res.to(dev)
+    outs = []
+    for _ in range(3):
+        outs.append(ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd))
+        assert ops.L.load().mgd_last_kernel() == b"conv_gather_gemm(latency form)"
+    plain = ops.conv_fwd(xd, pk)                       # no bias / activation / residual
+    # other operands through the same workspace right behind: a partial tile read stale (from the previous launch, out of
+    # another XCD's cache) would reproduce the OLD sums
+    x2 = bf(torch.randn(N, H, W, Ci, generator=g))
+    other = ops.conv_fwd(x2.to(dev), pk)
+    again = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
+    y2_ref = _ref_conv(x2, w, k, s)
+    ops.LATENCY = False
+    try:
+        regular = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
+        assert ops.L.load().mgd_last_kernel() != b"conv_gather_gemm(latency form)"
+    finally:
+        ops.LATENCY = True
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    tol = 0.02 * ref.abs().max().item() + 1e-3
+    assert (outs[0].float().cpu() - ref).abs().max().item() <= tol
+    assert (plain.float().cpu() - (y_ref - bias)).abs().max().item() <= 0.02 * y_ref.abs().max().item() + 1e-3
+    assert (other.float().cpu() - y2_ref).abs().max().item() <= 0.02 * y2_ref.abs().max().item() + 1e-3
+    assert torch.equal(again, outs[0])
+    assert (outs[0].float() - regular.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    if ranges > 1:
+        import ctypes as Ct
+        tickets = (Ct.c_uint32 * 4096)()
+        ops.L.check(ops.L.load().mgd_latency_tickets(tickets), "latency_tickets")
+        assert not any(tickets)                                                  # left at zero
 
 
 @pytest.mark.parametrize("N,H,W,Ci,Co,k,s", [(2, 20, 20, 64, 128, 3, 1), (2, 24, 24, 32, 64, 3, 2), (3, 19, 19, 256, 128, 1, 1),
