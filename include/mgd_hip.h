@@ -165,6 +165,10 @@ int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream);
  * epilogue; mgd_stem_wgrad is the direct fp32 kernel (the engine uses mgd_stem_im2col + mgd_conv_wgrad instead). */
 int mgd_stem_fwd(const float* image, const float* w, void* y, float* stats, int stats_replicas, int N, int H,
                  int W, void* stream);
+/* BatchNorm-folded inference form of the stem (w pre-scaled by gamma / sqrt(moving_var + eps), bias = the BN shift):
+ * y = LeakyReLU(act_slope)(conv + bias), bf16 - the DarknetConv2D_BN_Leaky of models/layers.py:88-95 in one launch. */
+int mgd_stem_fwd_act(const float* image, const float* w, const float* bias, float act_slope, void* y, int N, int H, int W,
+                     void* stream);
 int mgd_stem_wgrad(const float* image, const void* dy, float* dw, int N, int H, int W, void* stream);
 /* mgd_stem_wgrad with the stem's BatchNorm + LeakyReLU backward (layers.py:94-95) applied on the fly: takes da (gradient
  * wrt the activated stem output) and y (raw stem output) instead of dy, the per-channel scale/shift/mean/invstd of the

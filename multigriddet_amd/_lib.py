@@ -103,7 +103,7 @@ class DecodeCfg(C.Structure):
 
 # every symbol include/mgd_hip.h declares
 EXPORTS = [
-    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_debug_stamps", "mgd_latency_workspace", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_stem_fwd", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
+    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_debug_stamps", "mgd_latency_workspace", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_stem_fwd", "mgd_stem_fwd_act", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
     "mgd_pack_weights", "mgd_pack_weights_batch", "mgd_stem_im2col", "mgd_bn_finalize", "mgd_bn_act_fwd", "mgd_bn_act_fwd_fused", "mgd_bn_act_bwd_reduce", "mgd_bn_act_bwd_apply",
     "mgd_upsample_concat_fwd", "mgd_upsample_concat_bwd", "mgd_bias_grad", "mgd_f32_to_bf16", "mgd_bf16_to_f32",
     "mgd_adam_step", "mgd_adam_step_dev", "mgd_sgd_step", "mgd_build_targets_workspace_size", "mgd_build_targets",
@@ -128,6 +128,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.mgd_last_error.restype = C.c_char_p
     lib.mgd_last_kernel.restype = C.c_char_p
+    lib.mgd_stem_fwd_act.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     for name in ("mgd_build_targets_workspace_size", "mgd_loss_workspace_size", "mgd_decode_workspace_size",
                  "mgd_nms_workspace_size", "mgd_wbf_workspace_size", "mgd_letterbox_workspace_size"):
         getattr(lib, name).restype = C.c_size_t

@@ -1916,6 +1916,10 @@ __global__ __launch_bounds__(256) void conv_gemm11_kernel(GemmArgs a) {
 
   make_row_tables(a, pix0, tid, BMP, row_dst, row_src);
   lds_barrier();
+  // the residual rows of the tile are requested now: their round trip runs under the K-loop instead of in front of the
+  // stores (register loads next to the LDS-DMA stream only make the counted waits stricter: each kind retires in order)
+  Epi epi;
+  epi.prefetch(a, row_dst, co0, tid, false);
   const int rlo = tid >> 3;
   const int kc = (tid & 7) ^ (rlo & 7);
   unsigned xoff[XCH], vmask[XCH];
@@ -2057,8 +2061,7 @@ __global__ __launch_bounds__(256) void conv_gemm11_kernel(GemmArgs a) {
     }
     if (tid == 0) a.tickets[tile] = 0u;
   }
-  Epi epi;
-  epi.template run_grouped<Epi::EPC>(a, acc, smem, row_dst, co0, tid);
+  epi.template run<false, false>(a, acc, smem, row_dst, co0, tid);
 }
 
 template <int NT, int NST>
@@ -3116,7 +3119,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
 // (bf16-rounded image and weights, fp32 accumulation), reads 71 MB + writes 378 MB instead of 71+378 + 378+378 MB.
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                        bf16_t* __restrict__ y, float* stats, int reps, int N, int H,
-                                                       int W) {
+                                                       int W, const float* __restrict__ bias, float act_slope) {
   constexpr int TH = 4, TW = 64, PR = TH + 2, PCF = (TW + 2) * 3;      // patch rows, floats per patch row
   __shared__ float patch[PR * PCF];
   __shared__ float red[4][2][32];
@@ -3146,6 +3149,12 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     int k = fq * 8 + i;
     koff[i] = k < 27 ? (k / 9) * PCF + (k % 9) : -1;
   }
+  // folded inference (mgd_stem_fwd_act): the BatchNorm shift of this lane's eight channels, LeakyReLU on (acc + shift)
+  float bsh[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bsh[m][r] = bias ? bias[fq * 8 + m * 4 + r] : 0.f;
   float s1[2][4], s2[2][4];                        // BatchNorm statistics, carried over all tiles of the block
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -3202,6 +3211,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = acc[r] + bsh[m][r];
+            acc[r] = z > 0.f ? z : z * act_slope;
+          }
+        }
         uint2 pk;
         pk.x = pack2bf(acc[0], acc[1]);
         pk.y = pack2bf(acc[2], acc[3]);
@@ -4180,8 +4196,20 @@ extern "C" int mgd_stem_fwd(const float* image, const float* w, void* y, float* 
   long long grid = (long long)N * ((H + 3) / 4) * ((W + 63) / 64);
   if (grid > 256 * 8) grid = 256 * 8;               // persistent blocks: the statistics leave once per block
   hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, image, w, (bf16_t*)y, stats,
-                     stats_replicas > 0 ? stats_replicas : 1, N, H, W);
+                     stats_replicas > 0 ? stats_replicas : 1, N, H, W, (const float*)nullptr, 0.f);
   MGD_CHECK_LAUNCH("stem_fwd");
+  return MGD_OK;
+}
+
+extern "C" int mgd_stem_fwd_act(const float* image, const float* w, const float* bias, float act_slope, void* y, int N,
+                                int H, int W, void* stream) {
+  MGD_REQUIRE(image && w && bias && y, "stem_fwd_act: null pointer");
+  MGD_REQUIRE(N >= 1 && H >= 1 && W >= 1 && (long long)N * H * W * 3 < (1ll << 31), "stem_fwd_act: N=%d H=%d W=%d", N, H, W);
+  long long grid = (long long)N * ((H + 3) / 4) * ((W + 63) / 64);
+  if (grid > 256 * 8) grid = 256 * 8;
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, image, w, (bf16_t*)y,
+                     (float*)nullptr, 1, N, H, W, bias, act_slope);
+  MGD_CHECK_LAUNCH("stem_fwd_act");
   return MGD_OK;
 }
 

@@ -336,7 +336,11 @@ class Network:
         cv = self.layers[i]
         tr = self._bn_training(cv)
         y = A["y"][i]
-        if getattr(self, "folded", False) and not tr and cv.role != "stem":
+        if getattr(self, "folded", False) and not tr and cv.role == "stem":
+            n = cv.cout * cv.T * cv.cin
+            return self.O.stem_fwd_act(x, self._fold_w[cv.off_w:cv.off_w + n], self._fold_shift[cv.idx], ops.LEAKY_SLOPE,
+                                       out=A["a"][i])
+        if getattr(self, "folded", False) and not tr:
             return self.O.conv_fwd(x, cv.pk, out=A["a"][i], bias=self._fold_shift[cv.idx], act_slope=ops.LEAKY_SLOPE,
                                 addend=residual, wimg=self._fold_imgs[cv.idx])
         if cv.role == "stem":       # matrix-core stem straight from the fp32 image (no im2col image in the forward pass)
@@ -355,7 +359,8 @@ class Network:
             raise RuntimeError("training forward with fold_bn on: call fold_bn(False) first")
         A = self.arena(B, H, W)
         A["image"] = images
-        self.stats_all.zero_()
+        if self.training:
+            self.stats_all.zero_()              # (a launch of its own: not in front of an inference forward)
         x = self._conv_bn_act(A, 0, images)
         i = 1
         feats = {}

@@ -368,6 +368,16 @@ def stem_fwd(image, w, out=None, stats=None):
     return out
 
 
+def stem_fwd_act(image, w, bias, act_slope, out=None):
+    """BatchNorm-folded inference stem: LeakyReLU(conv(image, w) + bias), w pre-scaled, bias = the BN shift."""
+    N, H, W, _ = image.shape
+    if out is None:
+        out = torch.empty(N, H, W, 32, dtype=torch.bfloat16, device=image.device)
+    L.check(L.load().mgd_stem_fwd_act(L.ptr(image), L.ptr(w), L.ptr(bias), float(act_slope), L.ptr(out), N, H, W, L.stream_ptr()),
+            "stem_fwd_act")
+    return out
+
+
 def stem_wgrad(image, dy, dw):
     N, H, W, _ = image.shape
     L.check(L.load().mgd_stem_wgrad(L.ptr(image), L.ptr(dy), L.ptr(dw), N, H, W, L.stream_ptr()), "stem_wgrad")
