@@ -2416,7 +2416,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / WI, wi = wave % WI;
 
-  int b = blockIdx.x;
+  // the blocks of one pixel range (all channel tiles x taps: they stage the same dy / input rows at about the same time) get
+  // consecutive logical ids = one XCD, so that the re-reads hit its L2 (MGD_DBG & 65536: plain block order)
+  int b = (a.dbg & 65536) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   const int tco = b % a.tilesCo; b /= a.tilesCo;
   const int tci = b % a.tilesCi; b /= a.tilesCi;
   const int tap = b % a.ntaps;
@@ -2647,7 +2649,9 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / WI, wi = wave % WI;
 
-  int b = blockIdx.x;
+  // the blocks of one pixel range (all channel tiles x taps: they stage the same dy / input rows at about the same time) get
+  // consecutive logical ids = one XCD, so that the re-reads hit its L2 (MGD_DBG & 65536: plain block order)
+  int b = (a.dbg & 65536) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   const int tco = b % a.tilesCo; b /= a.tilesCo;
   const int tci = b % a.tilesCi; b /= a.tilesCi;
   const int tap = b % a.ntaps;
@@ -2905,7 +2909,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave >> 1, wi = wave & 1;
-  int bx = blockIdx.x;
+  int bx = (a.dbg & 65536) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);   // one split's blocks on one XCD (see conv_wgrad2_kernel)
   const int tco = bx % a.tilesCo; bx /= a.tilesCo;
   int ci0 = 0, dh = 0;
   if (ROW) { ci0 = (bx % a.tilesCi) * BCI; bx /= a.tilesCi; dh = bx % 3; bx /= 3; }
