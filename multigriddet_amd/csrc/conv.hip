@@ -2633,7 +2633,10 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 //    map of ITS tap over one image (H*W bits, <= 23 words at 76 x 76... 181 words) in LDS once, and a staged input row costs an
 //    index update, an LDS word, a bit test and a select per K-step.
 // Same tiles, ring, transposed fragment reads and atomic epilogue as v2.
-template <int WC, int WI, int MT, int NT>
+// NR: ring depth.  Both operands come by LDS-DMA, so a wave's vector-memory operations retire in order and a counted wait is
+// exact: NR >= 3 leaves NR - 2 whole stages in flight across the barrier (dummy stages behind the last step - the descriptors'
+// num_records have run out, every lane is out of range: no traffic, same count).
+template <int WC, int WI, int MT, int NT, int NR = 2>
 __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
   constexpr int BCO = WC * MT * 16;
   constexpr int BCI = WI * NT * 16;
@@ -2644,7 +2647,8 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
   constexpr int STAGE = 64 * (RBO + RBI);
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned* mbits = (unsigned*)(smem + 2 * STAGE);
+  constexpr int GRP = OCH + ICH;                       // LDS-DMA instructions per wave and stage
+  unsigned* mbits = (unsigned*)(smem + NR * STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / WI, wi = wave % WI;
@@ -2747,9 +2751,15 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  prep();
-  if (nk > 0) fire(0);
-  prep();                   // offsets of step 1
+  if constexpr (NR == 2) {
+    prep();
+    if (nk > 0) fire(0);
+    prep();                   // offsets of step 1
+  } else {
+#pragma unroll
+    for (int st = 0; st < NR - 1; ++st) { prep(); fire(st); }
+    prep();                   // offsets of stage NR - 1
+  }
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
   int o_rd[2][2][MT], i_rd[2][2][NT];
 #pragma unroll
@@ -2776,20 +2786,23 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
     }
   auto kstep = [&](auto bc, int ks) {
     constexpr int BUF = decltype(bc)::value;
-    wait_vmcnt<0>();
+    wait_vmcnt<(NR - 2) * GRP>();
     __builtin_amdgcn_s_barrier();
     const bool more = ks + 1 < nk;
     s16x4 fa[2][MT][2], fb[2][NT][2];
+    // the ring slot as the instruction's immediate offset where it fits its 16 bits, else added to the address
+    constexpr int IMM = BUF * STAGE < 65536 ? BUF * STAGE : 0;
+    constexpr unsigned EXTRA = (unsigned)(BUF * STAGE - IMM);
     auto read_half = [&](int kk) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        tr_read_asm<BUF * STAGE>(fa[kk][m][0], (unsigned)o_rd[kk][0][m]);
-        tr_read_asm<BUF * STAGE>(fa[kk][m][1], (unsigned)o_rd[kk][1][m]);
+        tr_read_asm<IMM>(fa[kk][m][0], (unsigned)o_rd[kk][0][m] + EXTRA);
+        tr_read_asm<IMM>(fa[kk][m][1], (unsigned)o_rd[kk][1][m] + EXTRA);
       }
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        tr_read_asm<BUF * STAGE>(fb[kk][n][0], (unsigned)i_rd[kk][0][n]);
-        tr_read_asm<BUF * STAGE>(fb[kk][n][1], (unsigned)i_rd[kk][1][n]);
+        tr_read_asm<IMM>(fb[kk][n][0], (unsigned)i_rd[kk][0][n] + EXTRA);
+        tr_read_asm<IMM>(fb[kk][n][1], (unsigned)i_rd[kk][1][n] + EXTRA);
       }
     };
     auto mfma_half = [&](int kk) {
@@ -2808,7 +2821,8 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
         }
       }
     };
-    if (more) fire(BUF ^ 1);
+    if constexpr (NR == 2) { if (more) fire(BUF ^ 1); }
+    else fire((BUF + NR - 1) % NR);          // into the slot every wave left before this barrier (a dummy stage past the end)
     read_half(0);
     wait_lgkm_dyn(0);
     read_half(1);          // in flight under the MFMAs of the first half
@@ -2817,9 +2831,19 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
     wait_lgkm_dyn(0);
     mfma_half(1);
   };
-  for (int ks = 0; ks < nk; ks += 2) {
-    kstep(std::integral_constant<int, 0>{}, ks);
-    if (ks + 1 < nk) kstep(std::integral_constant<int, 1>{}, ks + 1);
+  if constexpr (NR == 2) {
+    for (int ks = 0; ks < nk; ks += 2) {
+      kstep(std::integral_constant<int, 0>{}, ks);
+      if (ks + 1 < nk) kstep(std::integral_constant<int, 1>{}, ks + 1);
+    }
+  } else {
+    for (int ks = 0; ks < nk; ks += NR) {
+      kstep(std::integral_constant<int, 0>{}, ks);
+      if (ks + 1 < nk) kstep(std::integral_constant<int, 1>{}, ks + 1);
+      if (ks + 2 < nk) kstep(std::integral_constant<int, 2>{}, ks + 2);
+      if constexpr (NR >= 4) { if (ks + 3 < nk) kstep(std::integral_constant<int, 3>{}, ks + 3); }
+    }
+    wait_vmcnt<0>();                          // the dummy stages' zero writes land before the wave ends
   }
   const int fr = lane & 15, fq = lane >> 4;
   if (a.dbg & 32) return;
@@ -3725,13 +3749,13 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   return 0;
 }
 
-template <int WC, int WI, int MT, int NT>
+template <int WC, int WI, int MT, int NT, int NR = 2>
 int launch_wgrad4(WgradArgs& a, hipStream_t st) {
   constexpr int BCO = WC * MT * 16, BCI = WI * NT * 16;
   a.tilesCo = cdiv(a.Co, BCO);
   a.tilesCi = cdiv(a.Ci, BCI);
-  size_t lds = (size_t)64 * (BCO + BCI) * 2 * 2 + (size_t)((a.Hg * a.Wg + 31) / 32) * 4 + 16;   // ring + the tap's bit map
-  auto k = conv_wgrad4_kernel<WC, WI, MT, NT>;
+  size_t lds = (size_t)64 * (BCO + BCI) * 2 * NR + (size_t)((a.Hg * a.Wg + 31) / 32) * 4 + 16;   // ring + the tap's bit map
+  auto k = conv_wgrad4_kernel<WC, WI, MT, NT, NR>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
@@ -4176,9 +4200,21 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
   const bool lin = d->in_stride == 1 && d->Hs == d->Hg && d->Ws == d->Wg &&
                    (long long)a.chunk * (co > ci ? co : ci) * 2 < (1ll << 31) && d->Hg * d->Wg <= 64 * 1024;
   if (w4 && lin && co > 32 && ci > 32 && (wtile <= 1 || !(co > 64 && ci > 64))) {
-    if (co > 64 && ci > 64 && wtile == 0) launch_wgrad4<2, 2, 4, 4>(a, st);
-    else if (co > 64 && ci > 64) launch_wgrad4<2, 2, 4, 2>(a, st);
-    else launch_wgrad4<2, 2, 2, 2>(a, st);
+    // ring depth (MGD_WGRAD_RING; 0 = by layer): the 3x3 launches have nine tap blocks per tile and fill every block slot -
+    // there three blocks per CU with a 2-stage ring beat two with three stages (128->256 at 76x76: 86.5 against 108.6 us, one
+    // block with four stages 133.4); the 1x1 launches do not fill the slots and take the deeper ring (26.1 -> 21.6 us)
+    static int ring_env = -1;
+    if (ring_env < 0) { const char* e = getenv("MGD_WGRAD_RING"); ring_env = e ? atoi(e) : 0; }
+    const int ring = ring_env ? ring_env : (d->ntaps == 1 ? 3 : 2);
+    if (co > 64 && ci > 64 && wtile == 0) {
+      if (ring == 3) launch_wgrad4<2, 2, 4, 4, 3>(a, st); else if (ring == 4) launch_wgrad4<2, 2, 4, 4, 4>(a, st);
+      else launch_wgrad4<2, 2, 4, 4>(a, st);
+    } else if (co > 64 && ci > 64) {
+      if (ring == 3) launch_wgrad4<2, 2, 4, 2, 3>(a, st); else if (ring == 4) launch_wgrad4<2, 2, 4, 2, 4>(a, st);
+      else launch_wgrad4<2, 2, 4, 2>(a, st);
+    } else {
+      if (ring == 3) launch_wgrad4<2, 2, 2, 2, 3>(a, st); else launch_wgrad4<2, 2, 2, 2>(a, st);
+    }
     MGD_CHECK_LAUNCH("conv_wgrad(descriptor-addressed)");
     return MGD_OK;
   }
