@@ -2636,15 +2636,20 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 // NR: ring depth.  Both operands come by LDS-DMA, so a wave's vector-memory operations retire in order and a counted wait is
 // exact: NR >= 3 leaves NR - 2 whole stages in flight across the barrier (dummy stages behind the last step - the descriptors'
 // num_records have run out, every lane is out of range: no traffic, same count).
-template <int WC, int WI, int MT, int NT, int NR = 2>
+// KP: pixels per K-step (64 or 32).  32 halves the ring, so that a 128 x 128 tile (256 bytes of LDS-DMA per MFMA instead of the
+// 384 of 128 x 64) still runs three blocks per CU: its fragment reads are then pipelined over the two halves of the channel
+// rows instead of the two 32-pixel halves of the step.
+template <int WC, int WI, int MT, int NT, int NR = 2, int KP = 64>
 __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
   constexpr int BCO = WC * MT * 16;
   constexpr int BCI = WI * NT * 16;
   static_assert(WC * WI == 4, "4 waves");
   constexpr int RBO = BCO * 2, RBI = BCI * 2;
-  constexpr int OCH = RBO / 64, ICH = RBI / 64;        // LDS-DMA instructions per wave per stage
+  static_assert(KP == 64 || (KP == 32 && MT % 2 == 0), "pixels per K-step");
+  constexpr int KK = KP / 32;                          // 32-pixel MFMA k-steps per stage
+  constexpr int OCH = KP * RBO / 4096, ICH = KP * RBI / 4096;   // LDS-DMA instructions per wave per stage
   constexpr int ORPI = 1024 / RBO, IRPI = 1024 / RBI;  // rows per wave-instruction
-  constexpr int STAGE = 64 * (RBO + RBI);
+  constexpr int STAGE = KP * (RBO + RBI);
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int GRP = OCH + ICH;                       // LDS-DMA instructions per wave and stage
@@ -2665,7 +2670,7 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
   const int dw = (int)((a.tapcode >> (4 * tap + 2)) & 3) - 1;
   const int pbeg = split * a.chunk;
   const int pend = min(a.P, pbeg + a.chunk);
-  const int nk = (pend - pbeg + 63) / 64;
+  const int nk = (pend - pbeg + KP - 1) / KP;
   const int HW = a.Hg * a.Wg;
   const unsigned OOB = 0xFFFFFFF0u;
 
@@ -2686,7 +2691,7 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
   }
 
   // raw buffer descriptors over the block's pixel range; the K-loop moves base and num_records by one 64-pixel step
-  const long long dstep = (long long)a.Co * 128, xstep = (long long)a.Ci * 128;
+  const long long dstep = (long long)a.Co * 2 * KP, xstep = (long long)a.Ci * 2 * KP;
   unsigned long long obase = (unsigned long long)a.dy + (unsigned long long)((long long)pbeg * a.Co * 2);
   // (the input base may lie before the tensor for the upper taps of the first pixels: those rows are masked, never fetched)
   unsigned long long xbase = (unsigned long long)((long long)(unsigned long long)a.src + ((long long)pbeg + (long long)dh * a.Ws + dw) * a.Ci * 2);
@@ -2712,7 +2717,7 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
     const int c = co0 + ch * 8;
     o_off[i] = c < a.Co ? (unsigned)((r * a.Co + c) * 2) : OOB;
   }
-  const int adv = 64 % HW;
+  const int adv = KP % HW;
 #pragma unroll
   for (int i = 0; i < ICH; ++i) {
     const int r = (i * 4 + wave) * IRPI + i_rl;
@@ -2740,7 +2745,7 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
   auto fire = [&](int buf) {
     const unsigned ob = smem_a + buf * STAGE + wave * 1024;
     dma_rows_asm<OCH, 4096>(o_off, make_srd(obase, orec), ob);
-    dma_rows_asm<ICH, 4096>(xv, make_srd(xbase, xrec), ob + 64 * RBO);
+    dma_rows_asm<ICH, 4096>(xv, make_srd(xbase, xrec), ob + KP * RBO);
     obase += dstep; orec -= dstep;
     xbase += xstep; xrec -= xstep;
   };
@@ -2761,9 +2766,9 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
     prep();                   // offsets of stage NR - 1
   }
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
-  int o_rd[2][2][MT], i_rd[2][2][NT];
+  int o_rd[KK][2][MT], i_rd[KK][2][NT];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
+  for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int r0 = kk * 32 + 8 * g + qq + 4 * h;
@@ -2771,12 +2776,12 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
       for (int m = 0; m < MT; ++m) o_rd[kk][h][m] = r0 * RBO + (((wc * MT + m) ^ tr_swz(r0, RBO / 32)) * 32) + pp * 8;
 #pragma unroll
       for (int n = 0; n < NT; ++n)
-        i_rd[kk][h][n] = 64 * RBO + r0 * RBI + (((wi * NT + n) ^ tr_swz(r0, RBI / 32)) * 32) + pp * 8;
+        i_rd[kk][h][n] = KP * RBO + r0 * RBI + (((wi * NT + n) ^ tr_swz(r0, RBI / 32)) * 32) + pp * 8;
     }
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   // fragment read addresses are per-lane constants; the ring slot is an immediate offset (the loop is unrolled by two)
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
+  for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -2789,47 +2794,90 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
     wait_vmcnt<(NR - 2) * GRP>();
     __builtin_amdgcn_s_barrier();
     const bool more = ks + 1 < nk;
-    s16x4 fa[2][MT][2], fb[2][NT][2];
     // the ring slot as the instruction's immediate offset where it fits its 16 bits, else added to the address
     constexpr int IMM = BUF * STAGE < 65536 ? BUF * STAGE : 0;
     constexpr unsigned EXTRA = (unsigned)(BUF * STAGE - IMM);
-    auto read_half = [&](int kk) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        tr_read_asm<IMM>(fa[kk][m][0], (unsigned)o_rd[kk][0][m] + EXTRA);
-        tr_read_asm<IMM>(fa[kk][m][1], (unsigned)o_rd[kk][1][m] + EXTRA);
-      }
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        tr_read_asm<IMM>(fb[kk][n][0], (unsigned)i_rd[kk][0][n] + EXTRA);
-        tr_read_asm<IMM>(fb[kk][n][1], (unsigned)i_rd[kk][1][n] + EXTRA);
-      }
-    };
-    auto mfma_half = [&](int kk) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) { touch(fa[kk][m][0]); touch(fa[kk][m][1]); }
-#pragma unroll
-      for (int n = 0; n < NT; ++n) { touch(fb[kk][n][0]); touch(fb[kk][n][1]); }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        s16x8 av = __builtin_shufflevector(fa[kk][m][0], fa[kk][m][1], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          s16x8 bv = __builtin_shufflevector(fb[kk][n][0], fb[kk][n][1], 0, 1, 2, 3, 4, 5, 6, 7);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
-                                                             acc[m][n], 0, 0, 0);
-        }
-      }
-    };
     if constexpr (NR == 2) { if (more) fire(BUF ^ 1); }
     else fire((BUF + NR - 1) % NR);          // into the slot every wave left before this barrier (a dummy stage past the end)
-    read_half(0);
-    wait_lgkm_dyn(0);
-    read_half(1);          // in flight under the MFMAs of the first half
-    mfma_half(0);
-    prep();                // offsets of step ks + 2 (its LDS word is back long before the next fire)
-    wait_lgkm_dyn(0);
-    mfma_half(1);
+    if constexpr (KK == 2) {
+      s16x4 fa[2][MT][2], fb[2][NT][2];
+      auto read_half = [&](int kk) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          tr_read_asm<IMM>(fa[kk][m][0], (unsigned)o_rd[kk][0][m] + EXTRA);
+          tr_read_asm<IMM>(fa[kk][m][1], (unsigned)o_rd[kk][1][m] + EXTRA);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          tr_read_asm<IMM>(fb[kk][n][0], (unsigned)i_rd[kk][0][n] + EXTRA);
+          tr_read_asm<IMM>(fb[kk][n][1], (unsigned)i_rd[kk][1][n] + EXTRA);
+        }
+      };
+      auto mfma_half = [&](int kk) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { touch(fa[kk][m][0]); touch(fa[kk][m][1]); }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { touch(fb[kk][n][0]); touch(fb[kk][n][1]); }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          s16x8 av = __builtin_shufflevector(fa[kk][m][0], fa[kk][m][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            s16x8 bv = __builtin_shufflevector(fb[kk][n][0], fb[kk][n][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                               acc[m][n], 0, 0, 0);
+          }
+        }
+      };
+      read_half(0);
+      wait_lgkm_dyn(0);
+      read_half(1);          // in flight under the MFMAs of the first half
+      mfma_half(0);
+      prep();                // offsets of step ks + 2 (its LDS word is back long before the next fire)
+      wait_lgkm_dyn(0);
+      mfma_half(1);
+    } else {
+      // one 32-pixel k-step per stage: the halves are the lower / upper channel-row tiles of the wave
+      constexpr int MH = MT / 2;
+      s16x4 fa[MT][2], fb[NT][2];
+      auto read_rows = [&](int h) {
+#pragma unroll
+        for (int m = h * MH; m < (h + 1) * MH; ++m) {
+          tr_read_asm<IMM>(fa[m][0], (unsigned)o_rd[0][0][m] + EXTRA);
+          tr_read_asm<IMM>(fa[m][1], (unsigned)o_rd[0][1][m] + EXTRA);
+        }
+      };
+      auto mfma_rows = [&](int h) {
+#pragma unroll
+        for (int m = h * MH; m < (h + 1) * MH; ++m) { touch(fa[m][0]); touch(fa[m][1]); }
+        if (h == 0) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) { touch(fb[n][0]); touch(fb[n][1]); }
+        }
+#pragma unroll
+        for (int m = h * MH; m < (h + 1) * MH; ++m) {
+          s16x8 av = __builtin_shufflevector(fa[m][0], fa[m][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            s16x8 bv = __builtin_shufflevector(fb[n][0], fb[n][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                               acc[m][n], 0, 0, 0);
+          }
+        }
+      };
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        tr_read_asm<IMM>(fb[n][0], (unsigned)i_rd[0][0][n] + EXTRA);
+        tr_read_asm<IMM>(fb[n][1], (unsigned)i_rd[0][1][n] + EXTRA);
+      }
+      read_rows(0);
+      wait_lgkm_dyn(0);
+      read_rows(1);          // in flight under the MFMAs of the lower rows
+      mfma_rows(0);
+      prep();
+      wait_lgkm_dyn(0);
+      mfma_rows(1);
+    }
   };
   if constexpr (NR == 2) {
     for (int ks = 0; ks < nk; ks += 2) {
@@ -3749,13 +3797,13 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   return 0;
 }
 
-template <int WC, int WI, int MT, int NT, int NR = 2>
+template <int WC, int WI, int MT, int NT, int NR = 2, int KP = 64>
 int launch_wgrad4(WgradArgs& a, hipStream_t st) {
   constexpr int BCO = WC * MT * 16, BCI = WI * NT * 16;
   a.tilesCo = cdiv(a.Co, BCO);
   a.tilesCi = cdiv(a.Ci, BCI);
-  size_t lds = (size_t)64 * (BCO + BCI) * 2 * NR + (size_t)((a.Hg * a.Wg + 31) / 32) * 4 + 16;   // ring + the tap's bit map
-  auto k = conv_wgrad4_kernel<WC, WI, MT, NT, NR>;
+  size_t lds = (size_t)KP * (BCO + BCI) * 2 * NR + (size_t)((a.Hg * a.Wg + 31) / 32) * 4 + 16;   // ring + the tap's bit map
+  auto k = conv_wgrad4_kernel<WC, WI, MT, NT, NR, KP>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
@@ -4199,7 +4247,7 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
   if (w4 < 0) { const char* e = getenv("MGD_WGRAD4"); w4 = e ? atoi(e) : 1; }
   const bool lin = d->in_stride == 1 && d->Hs == d->Hg && d->Ws == d->Wg &&
                    (long long)a.chunk * (co > ci ? co : ci) * 2 < (1ll << 31) && d->Hg * d->Wg <= 64 * 1024;
-  if (w4 && lin && co > 32 && ci > 32 && (wtile <= 1 || !(co > 64 && ci > 64))) {
+  if (w4 && lin && co > 32 && ci > 32 && (wtile <= 1 || wtile >= 3 || !(co > 64 && ci > 64))) {
     // ring depth (MGD_WGRAD_RING; 0 = by layer): the 3x3 launches have nine tap blocks per tile and fill every block slot -
     // there three blocks per CU with a 2-stage ring beat two with three stages (128->256 at 76x76: 86.5 against 108.6 us, one
     // block with four stages 133.4); the 1x1 launches do not fill the slots and take the deeper ring (26.1 -> 21.6 us)
@@ -4209,6 +4257,10 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
     if (co > 64 && ci > 64 && wtile == 0) {
       if (ring == 3) launch_wgrad4<2, 2, 4, 4, 3>(a, st); else if (ring == 4) launch_wgrad4<2, 2, 4, 4, 4>(a, st);
       else launch_wgrad4<2, 2, 4, 4>(a, st);
+    } else if (co > 64 && ci > 64 && wtile == 3) {
+      launch_wgrad4<2, 2, 2, 2>(a, st);          // 64 x 64 tiles, five blocks per CU (experiment)
+    } else if (co > 64 && ci > 64 && wtile == 4) {
+      if (ring == 3) launch_wgrad4<2, 2, 4, 4, 3, 32>(a, st); else launch_wgrad4<2, 2, 4, 4, 2, 32>(a, st);   // 128 x 128, 32-pixel steps
     } else if (co > 64 && ci > 64) {
       if (ring == 3) launch_wgrad4<2, 2, 4, 2, 3>(a, st); else if (ring == 4) launch_wgrad4<2, 2, 4, 2, 4>(a, st);
       else launch_wgrad4<2, 2, 4, 2>(a, st);

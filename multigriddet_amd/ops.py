@@ -317,12 +317,12 @@ def wgrad_splits(P, co, ci, T, target_blocks=None):
     bci = 128 if ci > 64 else (64 if ci > 32 else 32)
     big = co > 64 and ci > 64
     if big and _WGRAD_TILE:
-        bco, bci = (128, 64) if _WGRAD_TILE == 1 else (64, 128)
+        bco, bci = {1: (128, 64), 2: (64, 128), 3: (64, 64), 4: (128, 128)}[_WGRAD_TILE]
     tiles = -(-co // bco) * -(-ci // bci) * T
     if target_blocks or T == 1:        # 1x1: ~1 block per CU, measured (short blocks, the epilogue dominates)
         target_blocks = target_blocks or 256
         return max(1, min(int(target_blocks / tiles + 0.5), -(-P // 256)))
-    slots = _WGRAD_BLOCKS if _WGRAD_BLOCKS else (768 if (big and _WGRAD_TILE == 1) else 512)
+    slots = _WGRAD_BLOCKS if _WGRAD_BLOCKS else (768 if (big and _WGRAD_TILE in (1, 4)) else 1280 if (big and _WGRAD_TILE == 3) else 512)
     atom = 0.05 * (bco * bci) / (128.0 * 128.0)
     best, best_cost = 1, None
     for sp in range(1, max(1, min(256, P // 256)) + 1):
