@@ -2696,6 +2696,8 @@ __global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
   // (the input base may lie before the tensor for the upper taps of the first pixels: those rows are masked, never fetched)
   unsigned long long xbase = (unsigned long long)((long long)(unsigned long long)a.src + ((long long)pbeg + (long long)dh * a.Ws + dw) * a.Ci * 2);
   long long orec = (long long)(pend - pbeg) * a.Co * 2, xrec = (long long)(pend - pbeg) * a.Ci * 2;
+  if (a.dbg & 131072) orec = xrec = 0;       // diagnostic: every LDS-DMA lane out of range - the K-loop without memory traffic
+  if (a.dbg & 262144) { orec = min(orec, 4096ll); xrec = min(xrec, 4096ll); }   // diagnostic: only the first rows are fetched (cache hits)
   auto make_srd = [&](unsigned long long base, long long rec) {
     i32x4 r;
     r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
