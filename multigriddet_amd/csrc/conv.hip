@@ -18,6 +18,12 @@
 
 namespace {
 
+// A kernel that promises at least two waves per SIMD has at most 256 registers, and only then does hipcc put MFMA
+// accumulators in ordinary VGPRs.  With launch_bounds(256) alone the budget is 512 (256 VGPR + 256 AGPR), the MFMAs are
+// selected in their AGPR form, and every loop whose accumulators cross a control-flow merge moves ALL of them AGPR <-> VGPR
+// each iteration: conv_wgrad4_kernel carried 32 v_accvgpr_write + 32 v_accvgpr_read per 16 MFMAs (round 3, ISA listing).
+#define MGD_VGPR_MFMA __attribute__((amdgpu_waves_per_eu(2)))
+
 constexpr int BK = 64;          // K elements per stage (2 MFMA k-steps of 32)
 constexpr int ROWB = BK * 2;    // bytes per LDS tile row (128)
 
@@ -163,7 +169,7 @@ __device__ __forceinline__ void dma_rows_asm(const unsigned (&v)[XCH], i32x4 srd
 }
 
 template <int WC, int WP, int MT, int NT, int NST>
-__global__ __launch_bounds__(64 * WC * WP) void conv_gemm2_kernel(GemmArgs a) {
+__global__ __launch_bounds__(64 * WC * WP) MGD_VGPR_MFMA void conv_gemm2_kernel(GemmArgs a) {
   constexpr int BNC = WC * MT * 16;
   constexpr int BMP = WP * NT * 16;
   constexpr int NTHR = 64 * WC * WP;      // 4 waves (128-pixel tile, 2 blocks/CU) or 8 waves (256-pixel tile)
@@ -1873,7 +1879,7 @@ int launch_gemm10(GemmArgs& a, hipStream_t st) {
 // bf16 output without BatchNorm statistics / fused reductions; (tap, channel) of a K-step wave-uniform (ntaps == 1 or
 // Ci % 64 == 0).  One block per CU (the ring is 144 KiB).
 template <int NT, int NST>
-__global__ __launch_bounds__(256) void conv_gemm11_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256) MGD_VGPR_MFMA void conv_gemm11_kernel(GemmArgs a) {
   constexpr int WC = 4, WP = 1, MT = 2, BNC = 128, BMP = 16 * NT, NTHR = 256;
   constexpr int RPR = NTHR / 8, XCH = BMP / RPR;             // 32 rows per DMA round; pixel pieces per wave and stage
   constexpr int PIXB = BMP * ROWB, STAGE = PIXB + 4 * 4096;  // pixel rows, then each wave's four weight fragments
@@ -2089,7 +2095,7 @@ int launch_gemm11(GemmArgs& a, hipStream_t st) {
 // stride 2) stages the haloed input patch ONCE (plain 16-byte loads, padded pixel pitch -> conflict-free
 // ds_read_b128), then runs the nine taps out of LDS.  Same epilogue as the other forms (GemmEpilogue).
 template <int CI, int CO, int S>
-__global__ __launch_bounds__(256) void conv_patch_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256) MGD_VGPR_MFMA void conv_patch_kernel(GemmArgs a) {
   constexpr int MT = CO / 16, KS = CI / 32, NT = 2 / S;
   constexpr int TR = 8 / S, TC = 16;                 // output tile: 8 x 16 pixels (4 x 16 at stride 2), NT rows per wave
   constexpr int BMP = TR * TC;
@@ -2402,7 +2408,7 @@ __device__ __forceinline__ void wait_lgkm_dyn(int n) {   // n is a compile-time 
 // Weight gradient v2: same MFMA/tr-read structure, operands staged by LDS-DMA into a 2-deep ring
 // (one raw barrier per 64-pixel K-step, the next stage's loads in flight during the MFMAs).
 template <int WC, int WI, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256) MGD_VGPR_MFMA void conv_wgrad2_kernel(WgradArgs a) {
   constexpr int BCO = WC * MT * 16;
   constexpr int BCI = WI * NT * 16;
   static_assert(WC * WI == 4, "4 waves");
@@ -2640,7 +2646,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 // 384 of 128 x 64) still runs three blocks per CU: its fragment reads are then pipelined over the two halves of the channel
 // rows instead of the two 32-pixel halves of the step.
 template <int WC, int WI, int MT, int NT, int NR = 2, int KP = 64>
-__global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256) MGD_VGPR_MFMA void conv_wgrad4_kernel(WgradArgs a) {
   constexpr int BCO = WC * MT * 16;
   constexpr int BCI = WI * NT * 16;
   static_assert(WC * WI == 4, "4 waves");
@@ -3195,7 +3201,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(Wgrad3Args a) {
 // words per lane (k = tap*3 + c; the three taps of a kernel row are nine consecutive floats of the patch row) -
 // K = 27 of 32, weights as two A fragments held in registers.  Same arithmetic as the im2col + GEMM path it replaces
 // (bf16-rounded image and weights, fp32 accumulation), reads 71 MB + writes 378 MB instead of 71+378 + 378+378 MB.
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+__global__ __launch_bounds__(256) MGD_VGPR_MFMA void stem_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                        bf16_t* __restrict__ y, float* stats, int reps, int N, int H,
                                                        int W, const float* __restrict__ bias, float act_slope) {
   constexpr int TH = 4, TW = 64, PR = TH + 2, PCF = (TW + 2) * 3;      // patch rows, floats per patch row
@@ -3358,7 +3364,7 @@ struct StemBn {
 };
 
 template <bool FUSE_BN>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(256) MGD_VGPR_MFMA void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy,
                                                          float* dw, int N, int H, int W, StemBn bn) {
   constexpr int TH = 4, TW = 64, PR = TH + 2, PCF = (TW + 2) * 3;
   __shared__ float patch[PR * PCF];
