@@ -2400,6 +2400,9 @@ __device__ __forceinline__ void wait_lgkm_dyn(int n) {   // n is a compile-time 
     case 10: asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); break;
     case 11: asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory"); break;
     case 12: asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt lgkmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); break;
     default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
   }
 }
@@ -2645,7 +2648,7 @@ __global__ __launch_bounds__(256) MGD_VGPR_MFMA void conv_wgrad2_kernel(WgradArg
 // KP: pixels per K-step (64 or 32).  32 halves the ring, so that a 128 x 128 tile (256 bytes of LDS-DMA per MFMA instead of the
 // 384 of 128 x 64) still runs three blocks per CU: its fragment reads are then pipelined over the two halves of the channel
 // rows instead of the two 32-pixel halves of the step.
-template <int WC, int WI, int MT, int NT, int NR = 2, int KP = 64>
+template <int WC, int WI, int MT, int NT, int NR = 2, int KP = 64, bool IL = false>
 __global__ __launch_bounds__(256) MGD_VGPR_MFMA void conv_wgrad4_kernel(WgradArgs a) {
   constexpr int BCO = WC * MT * 16;
   constexpr int BCI = WI * NT * 16;
@@ -2799,14 +2802,22 @@ __global__ __launch_bounds__(256) MGD_VGPR_MFMA void conv_wgrad4_kernel(WgradArg
     }
   auto kstep = [&](auto bc, int ks) {
     constexpr int BUF = decltype(bc)::value;
-    wait_vmcnt<(NR - 2) * GRP>();
-    __builtin_amdgcn_s_barrier();
+    if (!(a.dbg & 2097152)) {                  // diagnostic: 2097152 = no wait / barrier per K-step
+      wait_vmcnt<(NR - 2) * GRP>();
+      __builtin_amdgcn_s_barrier();
+    }
     const bool more = ks + 1 < nk;
+    const bool no_reads = a.dbg & 4194304;     // diagnostic: no fragment reads (MFMAs on whatever the registers hold)
     // the ring slot as the instruction's immediate offset where it fits its 16 bits, else added to the address
     constexpr int IMM = BUF * STAGE < 65536 ? BUF * STAGE : 0;
     constexpr unsigned EXTRA = (unsigned)(BUF * STAGE - IMM);
-    if constexpr (NR == 2) { if (more) fire(BUF ^ 1); }
-    else fire((BUF + NR - 1) % NR);          // into the slot every wave left before this barrier (a dummy stage past the end)
+    const bool fire_late = a.dbg & 1048576;    // diagnostics: 524288 = no LDS-DMA at all, 1048576 = issue it behind the first MFMAs
+    auto do_fire = [&]() {
+      if (a.dbg & 524288) return;
+      if constexpr (NR == 2) { if (more) fire(BUF ^ 1); }
+      else fire((BUF + NR - 1) % NR);        // into the slot every wave left before this barrier (a dummy stage past the end)
+    };
+    if (!fire_late) do_fire();
     if constexpr (KK == 2) {
       s16x4 fa[2][MT][2], fb[2][NT][2];
       auto read_half = [&](int kk) {
@@ -2837,13 +2848,65 @@ __global__ __launch_bounds__(256) MGD_VGPR_MFMA void conv_wgrad4_kernel(WgradArg
           }
         }
       };
-      read_half(0);
+      if constexpr (IL) {
+        // interleaved form: the pixel-operand fragments first, then the channel rows one by one; a row's MFMAs start as soon
+        // as ITS fragments are back (LDS operations return in order: counted lgkmcnt), and the second half's reads go out one
+        // or two per MFMA gap instead of as a burst in front of the first MFMA
+        constexpr int R1 = 2 * MT + 2 * NT, G = MT * NT;
+        auto rd = [&](int kk, int q) {           // read q of half kk: 0 .. 2NT-1 the pixel operand, then the rows
+          if (q < 2 * NT) tr_read_asm<IMM>(fb[kk][q >> 1][q & 1], (unsigned)i_rd[kk][q & 1][q >> 1] + EXTRA);
+          else { const int r = q - 2 * NT; tr_read_asm<IMM>(fa[kk][r >> 1][r & 1], (unsigned)o_rd[kk][r & 1][r >> 1] + EXTRA); }
+        };
+#pragma unroll
+        for (int q = 0; q < R1; ++q) rd(0, q);
+        int q1 = 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          wait_lgkm_dyn(2 * (MT - 1 - m) + q1);
+          if (m == 0) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { touch(fb[0][n][0]); touch(fb[0][n][1]); }
+          }
+          touch(fa[0][m][0]); touch(fa[0][m][1]);
+          s16x8 av = __builtin_shufflevector(fa[0][m][0], fa[0][m][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            s16x8 bv = __builtin_shufflevector(fb[0][n][0], fb[0][n][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                               acc[m][n], 0, 0, 0);
+            const int g = m * NT + n;
+            while (q1 < (g + 1) * R1 / G) { rd(1, q1); ++q1; }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        prep();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          wait_lgkm_dyn(2 * (MT - 1 - m));       // (the bit-map word prep() may have asked for is younger: waited for too)
+          if (m == 0) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { touch(fb[1][n][0]); touch(fb[1][n][1]); }
+          }
+          touch(fa[1][m][0]); touch(fa[1][m][1]);
+          s16x8 av = __builtin_shufflevector(fa[1][m][0], fa[1][m][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            s16x8 bv = __builtin_shufflevector(fb[1][n][0], fb[1][n][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                               acc[m][n], 0, 0, 0);
+          }
+        }
+        wait_lgkm_dyn(0);
+      } else {
+      if (!no_reads) read_half(0);
       wait_lgkm_dyn(0);
-      read_half(1);          // in flight under the MFMAs of the first half
+      if (!no_reads) read_half(1);          // in flight under the MFMAs of the first half
       mfma_half(0);
+      if (fire_late) do_fire();
       prep();                // offsets of step ks + 2 (its LDS word is back long before the next fire)
       wait_lgkm_dyn(0);
       mfma_half(1);
+      }
     } else {
       // one 32-pixel k-step per stage: the halves are the lower / upper channel-row tiles of the wave
       constexpr int MH = MT / 2;
@@ -3805,13 +3868,13 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   return 0;
 }
 
-template <int WC, int WI, int MT, int NT, int NR = 2, int KP = 64>
+template <int WC, int WI, int MT, int NT, int NR = 2, int KP = 64, bool IL = false>
 int launch_wgrad4(WgradArgs& a, hipStream_t st) {
   constexpr int BCO = WC * MT * 16, BCI = WI * NT * 16;
   a.tilesCo = cdiv(a.Co, BCO);
   a.tilesCi = cdiv(a.Ci, BCI);
   size_t lds = (size_t)KP * (BCO + BCI) * 2 * NR + (size_t)((a.Hg * a.Wg + 31) / 32) * 4 + 16;   // ring + the tap's bit map
-  auto k = conv_wgrad4_kernel<WC, WI, MT, NT, NR, KP>;
+  auto k = conv_wgrad4_kernel<WC, WI, MT, NT, NR, KP, IL>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
@@ -4270,7 +4333,10 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
     } else if (co > 64 && ci > 64 && wtile == 4) {
       if (ring == 3) launch_wgrad4<2, 2, 4, 4, 3, 32>(a, st); else launch_wgrad4<2, 2, 4, 4, 2, 32>(a, st);   // 128 x 128, 32-pixel steps
     } else if (co > 64 && ci > 64) {
+      static int il = -1;
+      if (il < 0) { const char* e = getenv("MGD_WGRAD_IL"); il = e ? atoi(e) : 0; }
       if (ring == 3) launch_wgrad4<2, 2, 4, 2, 3>(a, st); else if (ring == 4) launch_wgrad4<2, 2, 4, 2, 4>(a, st);
+      else if (il) launch_wgrad4<2, 2, 4, 2, 2, 64, true>(a, st);
       else launch_wgrad4<2, 2, 4, 2>(a, st);
     } else {
       if (ring == 3) launch_wgrad4<2, 2, 2, 2, 3>(a, st); else launch_wgrad4<2, 2, 2, 2>(a, st);
