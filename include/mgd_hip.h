@@ -117,6 +117,12 @@ int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream);
  * inside the same kernel, which ordinary (L2-cached) device memory does not guarantee.  *out / *capacity: the buffer and its
  * size (>= bytes).  Synchronises the device when it has to (re)allocate: call it once with the largest size before capturing
  * a stream.  mgd_latency_tickets: test hook, copies the 4096 tickets to the host. */
+/* Diagnostic: `blocks` workgroups of 4 waves each issue iters x nacc (8 or 16) independent v_mfma_f32_16x16x32_bf16 on register
+ * operands - the matrix pipe's ceiling at the clock the part holds under that load (tools/mfma_peak.py). */
+int mgd_debug_mfma_peak(float* out, int blocks, int iters, int nacc, void* stream);
+/* Diagnostic: the weight gradient's K-step rebuilt around that stream, one ingredient per `mode` bit (fragment reads, barrier,
+ * LDS-DMA issue, interleaved reads, s_setprio): what each costs next to 16 MFMAs (tools/mfma_peak.py). */
+int mgd_debug_wgrad_skeleton(float* out, int blocks, int iters, int mode, void* stream);
 int mgd_latency_workspace(int64_t bytes, void** out, int64_t* capacity);
 int mgd_latency_tickets(unsigned* out4096);
 

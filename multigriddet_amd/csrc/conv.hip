@@ -4481,6 +4481,215 @@ extern "C" int mgd_latency_tickets(unsigned* out4096) {
   return MGD_OK;
 }
 
+// Diagnostic: a bare MFMA stream (operands in registers, NACC independent accumulators per wave, no memory, no LDS) - the
+// matrix pipe's ceiling on this part at the clock it actually holds under that load.  tools/mfma_peak.py times it.
+template <int NACC>
+__global__ __launch_bounds__(256) MGD_VGPR_MFMA void mfma_peak_kernel(float* out, int iters) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (bf16_t)(0x3f80 + threadIdx.x + i); b[i] = (bf16_t)(0x3c00 + 3 * threadIdx.x + i); }
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  f32x4 t = acc[0];
+#pragma unroll
+  for (int i = 1; i < NACC; ++i) t += acc[i];
+  if (t[0] == 123.456f) out[threadIdx.x] = t[1] + t[2] + t[3];
+}
+
+// Diagnostic: the weight gradient's K-step rebuilt piece by piece around the bare MFMA stream (128 x 64 tile: 16 MFMAs, 24
+// transposed fragment reads, 6 LDS-DMA instructions and one barrier per wave and step; 48 KB of LDS so that three blocks share a
+// CU).  MODE bits: 1 = fragment reads (burst of 12, lgkmcnt(0), 12 under the first 8 MFMAs, lgkmcnt(0) - as conv_wgrad4_kernel),
+// 2 = s_barrier per step, 4 = six LDS-DMA instructions per step with every lane out of range, 8 = the reads one or two per MFMA
+// gap with counted waits instead, 16 = s_setprio 1 around the MFMAs.
+template <int MODE>
+__global__ __launch_bounds__(256) MGD_VGPR_MFMA void wgrad_skel_kernel(float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 48 * 1024 / 4; i += 256) ((unsigned*)smem)[i] = 0x3f803f80u + i;
+  __syncthreads();
+  constexpr int MT = 4, NT = 2;
+  const unsigned base = lds_addr(smem) + (lane & 3) * 8 + ((lane >> 2) & 15) * 288;   // 288-byte rows: the eight rows of a 32-lane group on disjoint banks
+  unsigned ra[2][MT][2], rb[2][NT][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) ra[kk][m][h] = base + kk * 8192 + h * 1024 + ((m ^ (lane & 3)) * 32);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) rb[kk][n][h] = base + 16384 + kk * 4096 + h * 1024 + ((n ^ (lane & 1)) * 32);
+    }
+  i32x4 srd;
+  srd[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)out);
+  srd[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(((unsigned long long)out >> 32) & 0xFFFFu));
+  srd[2] = 0;                                  // num_records 0: every lane out of range
+  srd[3] = 0x00020000;
+  unsigned vo4[4], vo2[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vo4[i] = lane * 16 + i * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) vo2[i] = lane * 16 + i * 64;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x4 fa[2][MT][2], fb[2][NT][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) fa[kk][m][0] = fa[kk][m][1] = s16x4{(short)(0x3f80 + lane), 1, 2, 3};
+#pragma unroll
+    for (int n = 0; n < NT; ++n) fb[kk][n][0] = fb[kk][n][1] = s16x4{(short)(0x3c00 + lane), 1, 2, 3};
+  }
+  auto mfma1 = [&](int kk, int m, int n) {
+    s16x8 av = __builtin_shufflevector(fa[kk][m][0], fa[kk][m][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    s16x8 bv = __builtin_shufflevector(fb[kk][n][0], fb[kk][n][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[m][n], 0, 0, 0);
+  };
+  auto rd = [&](int kk, int q) {
+    if (q < 2 * NT) tr_read_asm<0>(fb[kk][q >> 1][q & 1], rb[kk][q >> 1][q & 1]);
+    else { const int r = q - 2 * NT; tr_read_asm<0>(fa[kk][r >> 1][r & 1], ra[kk][r >> 1][r & 1]); }
+  };
+  auto touch_half = [&](int kk) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { touch(fa[kk][m][0]); touch(fa[kk][m][1]); }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { touch(fb[kk][n][0]); touch(fb[kk][n][1]); }
+  };
+  constexpr int R1 = 2 * MT + 2 * NT;
+  f32x4 stg[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) stg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    if (MODE & 2) __builtin_amdgcn_s_barrier();
+    if (MODE & 4) {
+      dma_rows_asm<4, 4096>(vo4, srd, lds_addr(smem) + wave * 1024);
+      dma_rows_asm<2, 4096>(vo2, srd, lds_addr(smem) + 16384 + wave * 1024);
+    }
+    if (MODE & 32) {                           // the same six pieces as register loads + ds_write_b128 of the previous step's
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr(smem) + 24576 + wave * 1024 + i * 4096 + lane * 16), "v"(stg[i]) : "memory");
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(stg[i]) : "v"(vo4[i & 3]), "s"(srd) : "memory");
+    }
+    if (MODE & 16) __builtin_amdgcn_s_setprio(1);
+    if ((MODE & 1) && !(MODE & 8)) {
+#pragma unroll
+      for (int q = 0; q < R1; ++q) rd(0, q);
+      wait_lgkm_dyn(0);
+#pragma unroll
+      for (int q = 0; q < R1; ++q) rd(1, q);
+      touch_half(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) mfma1(0, m, n);
+      wait_lgkm_dyn(0);
+      touch_half(1);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) mfma1(1, m, n);
+    } else if (MODE & 1) {
+#pragma unroll
+      for (int q = 0; q < R1; ++q) rd(0, q);
+      int q1 = 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        wait_lgkm_dyn(2 * (MT - 1 - m) + q1);
+        if (m == 0) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) { touch(fb[0][n][0]); touch(fb[0][n][1]); }
+        }
+        touch(fa[0][m][0]); touch(fa[0][m][1]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          mfma1(0, m, n);
+          const int g = m * NT + n;
+          while (q1 < (g + 1) * R1 / (MT * NT)) { rd(1, q1); ++q1; }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        wait_lgkm_dyn(2 * (MT - 1 - m));
+        if (m == 0) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) { touch(fb[1][n][0]); touch(fb[1][n][1]); }
+        }
+        touch(fa[1][m][0]); touch(fa[1][m][1]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) mfma1(1, m, n);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) mfma1(kk, m, n);
+    }
+    if (MODE & 16) __builtin_amdgcn_s_setprio(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  f32x4 t = acc[0][0];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) t += acc[m][n];
+  if (t[0] == 123.456f) out[threadIdx.x] = t[1] + t[2] + t[3];
+}
+
+template <int MODE>
+static void launch_skel(float* out, int blocks, int iters, hipStream_t st) {
+  auto k = wgrad_skel_kernel<MODE>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 48 * 1024, st, out, iters);
+}
+
+extern "C" int mgd_debug_wgrad_skeleton(float* out, int blocks, int iters, int mode, void* stream) {
+  MGD_REQUIRE(out && blocks >= 1 && iters >= 1, "wgrad_skeleton: arguments");
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case 0: launch_skel<0>(out, blocks, iters, st); break;
+    case 1: launch_skel<1>(out, blocks, iters, st); break;
+    case 2: launch_skel<2>(out, blocks, iters, st); break;
+    case 3: launch_skel<3>(out, blocks, iters, st); break;
+    case 4: launch_skel<4>(out, blocks, iters, st); break;
+    case 7: launch_skel<7>(out, blocks, iters, st); break;
+    case 9: launch_skel<9>(out, blocks, iters, st); break;
+    case 11: launch_skel<11>(out, blocks, iters, st); break;
+    case 15: launch_skel<15>(out, blocks, iters, st); break;
+    case 23: launch_skel<23>(out, blocks, iters, st); break;
+    case 31: launch_skel<31>(out, blocks, iters, st); break;
+    case 32: launch_skel<32>(out, blocks, iters, st); break;
+    case 35: launch_skel<35>(out, blocks, iters, st); break;
+    case 43: launch_skel<43>(out, blocks, iters, st); break;
+    default: MGD_REQUIRE(false, "wgrad_skeleton: mode %d not built", mode);
+  }
+  MGD_CHECK_LAUNCH("wgrad_skeleton");
+  return MGD_OK;
+}
+
+extern "C" int mgd_debug_mfma_peak(float* out, int blocks, int iters, int nacc, void* stream) {
+  MGD_REQUIRE(out && blocks >= 1 && iters >= 1, "mfma_peak: arguments");
+  if (nacc == 16) hipLaunchKernelGGL(mfma_peak_kernel<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
+  else hipLaunchKernelGGL(mfma_peak_kernel<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
+  MGD_CHECK_LAUNCH("mfma_peak");
+  return MGD_OK;
+}
+
 extern "C" int mgd_debug_stamps(unsigned long long* out16) {
   MGD_REQUIRE(out16, "debug_stamps: null pointer");
   unsigned long long z[24] = {0};
