@@ -4506,13 +4506,13 @@ __global__ __launch_bounds__(256) MGD_VGPR_MFMA void mfma_peak_kernel(float* out
 // CU).  MODE bits: 1 = fragment reads (burst of 12, lgkmcnt(0), 12 under the first 8 MFMAs, lgkmcnt(0) - as conv_wgrad4_kernel),
 // 2 = s_barrier per step, 4 = six LDS-DMA instructions per step with every lane out of range, 8 = the reads one or two per MFMA
 // gap with counted waits instead, 16 = s_setprio 1 around the MFMAs.
-template <int MODE>
-__global__ __launch_bounds__(256) MGD_VGPR_MFMA void wgrad_skel_kernel(float* out, int iters) {
+// MT x NT: 16 x 16 tiles per wave; NW waves per workgroup; D1 + D2 LDS-DMA instructions per wave and step; LKB KiB of LDS
+template <int MODE, int MT = 4, int NT = 2, int NW = 4, int D1 = 4, int D2 = 2, int LKB = 48>
+__global__ __launch_bounds__(64 * NW) MGD_VGPR_MFMA void wgrad_skel_kernel(float* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 48 * 1024 / 4; i += 256) ((unsigned*)smem)[i] = 0x3f803f80u + i;
+  for (int i = tid; i < 48 * 1024 / 4; i += 64 * NW) ((unsigned*)smem)[i] = 0x3f803f80u + i;
   __syncthreads();
-  constexpr int MT = 4, NT = 2;
   const unsigned base = lds_addr(smem) + (lane & 3) * 8 + ((lane >> 2) & 15) * 288;   // 288-byte rows: the eight rows of a 32-lane group on disjoint banks
   unsigned ra[2][MT][2], rb[2][NT][2];
 #pragma unroll
@@ -4529,11 +4529,11 @@ __global__ __launch_bounds__(256) MGD_VGPR_MFMA void wgrad_skel_kernel(float* ou
   srd[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(((unsigned long long)out >> 32) & 0xFFFFu));
   srd[2] = 0;                                  // num_records 0: every lane out of range
   srd[3] = 0x00020000;
-  unsigned vo4[4], vo2[2];
+  unsigned vo4[D1], vo2[D2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) vo4[i] = lane * 16 + i * 64;
+  for (int i = 0; i < D1; ++i) vo4[i] = lane * 16 + i * 64;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) vo2[i] = lane * 16 + i * 64;
+  for (int i = 0; i < D2; ++i) vo2[i] = lane * 16 + i * 64;
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -4570,18 +4570,18 @@ __global__ __launch_bounds__(256) MGD_VGPR_MFMA void wgrad_skel_kernel(float* ou
   for (int it = 0; it < iters; ++it) {
     if (MODE & 2) __builtin_amdgcn_s_barrier();
     if (MODE & 4) {
-      dma_rows_asm<4, 4096>(vo4, srd, lds_addr(smem) + wave * 1024);
-      dma_rows_asm<2, 4096>(vo2, srd, lds_addr(smem) + 16384 + wave * 1024);
+      dma_rows_asm<D1, 1024>(vo4, srd, lds_addr(smem) + (wave & 3) * 1024);
+      dma_rows_asm<D2, 1024>(vo2, srd, lds_addr(smem) + 16384 + (wave & 3) * 1024);
     }
     if (MODE & 32) {                           // the same six pieces as register loads + ds_write_b128 of the previous step's
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr(smem) + 24576 + wave * 1024 + i * 4096 + lane * 16), "v"(stg[i]) : "memory");
+        asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr(smem) + 24576 + (wave & 3) * 1024 + i * 4096 + lane * 16), "v"(stg[i]) : "memory");
       }
 #pragma unroll
       for (int i = 0; i < 6; ++i)
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(stg[i]) : "v"(vo4[i & 3]), "s"(srd) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(stg[i]) : "v"(vo4[i % D1]), "s"(srd) : "memory");
     }
     if (MODE & 16) __builtin_amdgcn_s_setprio(1);
     if ((MODE & 1) && !(MODE & 8)) {
@@ -4651,13 +4651,16 @@ __global__ __launch_bounds__(256) MGD_VGPR_MFMA void wgrad_skel_kernel(float* ou
   if (t[0] == 123.456f) out[threadIdx.x] = t[1] + t[2] + t[3];
 }
 
-template <int MODE>
+template <int MODE, int MT = 4, int NT = 2, int NW = 4, int D1 = 4, int D2 = 2, int LKB = 48>
 static void launch_skel(float* out, int blocks, int iters, hipStream_t st) {
-  auto k = wgrad_skel_kernel<MODE>;
-  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 48 * 1024, st, out, iters);
+  auto k = wgrad_skel_kernel<MODE, MT, NT, NW, D1, D2, LKB>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * NW), LKB * 1024, st, out, iters);
 }
 
+// mode = bits (see wgrad_skel_kernel) + 64 * shape: 0 = today's 128 x 64 tile (4 waves of 64 x 32, 6 LDS-DMA per wave and step,
+// 48 KB: three workgroups per CU); 1 = 256 x 128, 8 waves of 64 x 64, 6 LDS-DMA, 96 KB (one workgroup per CU); 2 = 256 x 256, 8
+// waves of 128 x 64, 8 LDS-DMA, 128 KB; 3 = 128 x 128, 4 waves of 64 x 64, 8 LDS-DMA, 64 KB (two workgroups per CU)
 extern "C" int mgd_debug_wgrad_skeleton(float* out, int blocks, int iters, int mode, void* stream) {
   MGD_REQUIRE(out && blocks >= 1 && iters >= 1, "wgrad_skeleton: arguments");
   hipStream_t st = (hipStream_t)stream;
@@ -4676,6 +4679,15 @@ extern "C" int mgd_debug_wgrad_skeleton(float* out, int blocks, int iters, int m
     case 32: launch_skel<32>(out, blocks, iters, st); break;
     case 35: launch_skel<35>(out, blocks, iters, st); break;
     case 43: launch_skel<43>(out, blocks, iters, st); break;
+    case 64 + 0: launch_skel<0, 4, 4, 8, 4, 2, 96>(out, blocks, iters, st); break;
+    case 64 + 7: launch_skel<7, 4, 4, 8, 4, 2, 96>(out, blocks, iters, st); break;
+    case 64 + 15: launch_skel<15, 4, 4, 8, 4, 2, 96>(out, blocks, iters, st); break;
+    case 128 + 0: launch_skel<0, 8, 4, 8, 4, 4, 128>(out, blocks, iters, st); break;
+    case 128 + 7: launch_skel<7, 8, 4, 8, 4, 4, 128>(out, blocks, iters, st); break;
+    case 128 + 15: launch_skel<15, 8, 4, 8, 4, 4, 128>(out, blocks, iters, st); break;
+    case 192 + 0: launch_skel<0, 4, 4, 4, 4, 4, 64>(out, blocks, iters, st); break;
+    case 192 + 7: launch_skel<7, 4, 4, 4, 4, 4, 64>(out, blocks, iters, st); break;
+    case 192 + 15: launch_skel<15, 4, 4, 4, 4, 4, 64>(out, blocks, iters, st); break;
     default: MGD_REQUIRE(false, "wgrad_skeleton: mode %d not built", mode);
   }
   MGD_CHECK_LAUNCH("wgrad_skeleton");

@@ -46,3 +46,24 @@ for mode in (0, 1, 9, 2, 4, 32, 3, 11, 7, 15, 23, 31, 35, 43):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 3
     print(f"mode {mode:2d} {names[mode]:52s}: {ms:7.3f} ms  {fl / ms / 1e9:7.0f} TFLOP/s", flush=True)
+
+print("candidate tiles (mode bits 7 = reads in bursts + barrier + LDS-DMA, 15 = reads interleaved):")
+shapes = {1: ("256 x 128, 8 waves of 64 x 64, 6 LDS-DMA, one workgroup per CU", 256, 8, 32),
+          2: ("256 x 256, 8 waves of 128 x 64, 8 LDS-DMA, one workgroup per CU", 256, 8, 64),
+          3: ("128 x 128, 4 waves of 64 x 64, 8 LDS-DMA, two workgroups per CU", 512, 4, 32)}
+for shp, (name, blocks, nw, mf) in shapes.items():
+    for bits in (0, 7, 15):
+        iters = 4000
+        fl = blocks * nw * iters * mf * 2.0 * 16 * 16 * 32
+        mode = 64 * shp + bits
+        for _ in range(2):
+            L.check(lib.mgd_debug_wgrad_skeleton(L.ptr(out), blocks, iters, mode, L.stream_ptr()), "skeleton")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            L.check(lib.mgd_debug_wgrad_skeleton(L.ptr(out), blocks, iters, mode, L.stream_ptr()), "skeleton")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        print(f"{name}, bits {bits:2d}: {ms:7.3f} ms  {fl / ms / 1e9:7.0f} TFLOP/s", flush=True)
