@@ -2370,8 +2370,16 @@ struct WgradArgs {
   int dbg;        // diagnostics (MGD_DBG): 16 = plain stores instead of atomics, 32 = no epilogue at all
 };
 
+// 32-byte chunk swizzle of the [pixel][channel] LDS tiles read with ds_read_b64_tr_b16.  A 32-lane group of that read
+// touches one chunk of each of the pixel rows {q, q + 8 : q = 0..3} (+4 for the upper half), and LDS has 64 banks = 256 bytes:
+// 256-byte rows all start on bank 0 and need eight distinct chunk slots; 128-byte rows alternate between the two bank halves,
+// so the FOUR rows of equal parity {0, 2, 8, 10} need four distinct slots; of 64-byte rows only {q, q + 8} share banks.
+// (Round 3: the 128- and 64-byte cases used the low bits of the 256-byte formula, which gives rows q and q + 8 the same slot:
+// every read of such a tile was a 2-way conflict, 24 % of the weight gradient's LDS cycles - SQ_LDS_BANK_CONFLICT.)
 __device__ __forceinline__ int tr_swz(int row, int nchunk32) {
-  return ((row & 3) | (((row >> 3) & 1) << 2)) & (nchunk32 - 1);
+  if (nchunk32 >= 8) return ((row & 3) | (((row >> 3) & 1) << 2)) & (nchunk32 - 1);
+  if (nchunk32 == 4) return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+  return nchunk32 == 2 ? (row >> 3) & 1 : 0;
 }
 
 __device__ __forceinline__ s16x4 ds_read_tr16(const unsigned char* p) {
