@@ -291,7 +291,7 @@ def main():
             "conv_gather_gemm(counted pipeline, ping-pong)": ("conv_gemm9_kernel<8,8,4,true> (256x128-tile gather-GEMM, 8 waves in ping-pong phases)", "conv_gemm9_kernel<8,"),
             "conv_gather_gemm(streaming ping-pong)": ("conv_gemm10_kernel (256-channel streaming ping-pong gather-GEMM)", "conv_gemm10_kernel"),
             "conv_wgrad(descriptor-addressed)": ("conv_wgrad4_kernel<2,2,4,2> (128x64-tile bf16 MFMA weight gradient, per-tap blocks, split-K, "
-                                                 "descriptor-addressed operands, three blocks per CU)", "conv_wgrad4_kernel<2, 2, 4, 2>"),
+                                                 "descriptor-addressed operands, three blocks per CU)", "conv_wgrad4_kernel<2, 2, 4, 2, 2,"),
             "conv_wgrad": ("conv_wgrad2_kernel (per-tap weight gradient, carried addresses: stride-2 layers)", "conv_wgrad2_kernel<2, 2, 4, 2>"),
         }
         step_ms = dt * 1e3 / args.steps
