@@ -13,6 +13,7 @@
 // channels of one pixel per accumulator tile - 8-byte packed bf16 pieces that are staged through LDS
 // and leave as whole 16-byte/256-byte NHWC rows.
 #include "common.h"
+#include <mutex>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -4462,6 +4463,8 @@ extern "C" int mgd_latency_workspace(int64_t bytes, void** out, int64_t* capacit
   MGD_REQUIRE(out && bytes >= 16384, "latency_workspace: at least the 16 KiB of tickets");
   static void* ws[64];
   static int64_t cap[64];
+  static std::mutex mu;                          // host threads of one process may share a device
+  std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   MGD_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "latency_workspace: device");
   if (cap[dev] < bytes) {
