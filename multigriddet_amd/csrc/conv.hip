@@ -2693,7 +2693,7 @@ __global__ __launch_bounds__(256) MGD_VGPR_MFMA void conv_wgrad4_kernel(WgradArg
   const unsigned OOB = 0xFFFFFFF0u;
 
   // bit q of the map: the tap's source pixel of output pixel q (of one image) lies inside the image
-  const bool masked = dh != 0 || dw != 0;
+  const bool masked = (dh != 0 || dw != 0) && !(a.dbg & 16777216);   // diagnostic 16777216: no border bit map (wrong sums at the borders)
   if (masked) {
     for (int w = tid; w < (HW + 31) / 32; w += 256) {
       const int q0 = w * 32;
@@ -2750,15 +2750,19 @@ __global__ __launch_bounds__(256) MGD_VGPR_MFMA void conv_wgrad4_kernel(WgradArg
 
   // prep(): the input rows' offsets of the NEXT stage to issue (bit test against the map), behind the first MFMAs of the
   // previous step; fire(): the six LDS-DMA instructions, right after the barrier, then the descriptors move on
-  unsigned xv[ICH];
+  // (the map word of a row is fetched one prep() AHEAD: its LDS round trip then lies under a whole K-step instead of in front
+  // of the select that needs it - with the fetch and its lgkmcnt(0) inside prep() the lookup cost 6 % of the kernel)
+  unsigned xv[ICH], xw[ICH];
+#pragma unroll
+  for (int i = 0; i < ICH; ++i) xw[i] = masked ? mbits[x_q[i] >> 5] : 0xFFFFFFFFu;
   auto prep = [&]() {
 #pragma unroll
     for (int i = 0; i < ICH; ++i) {
-      unsigned ok = 1u;
-      if (masked) ok = (mbits[x_q[i] >> 5] >> (x_q[i] & 31)) & 1u;
+      const unsigned ok = (xw[i] >> (x_q[i] & 31)) & 1u;
       xv[i] = ok ? x_off[i] : OOB;
       x_q[i] += adv;
       x_q[i] -= x_q[i] >= HW ? HW : 0;
+      if (masked) xw[i] = mbits[x_q[i] >> 5];
     }
   };
   const unsigned smem_a = lds_addr(smem);
