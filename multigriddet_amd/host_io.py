@@ -106,6 +106,10 @@ def worker_main(address, authkey_hex, shm_name):
     from multiprocessing.connection import Client
     from multiprocessing import shared_memory
     tune_host_allocators()
+    try:
+        os.nice(5)      # the trainer's own threads (600 kernel launches per step) come first when the cores are oversubscribed
+    except OSError:
+        pass
     conn = Client(address, family="AF_UNIX", authkey=bytes.fromhex(authkey_hex))
     shm = shared_memory.SharedMemory(name=shm_name)
     try:
