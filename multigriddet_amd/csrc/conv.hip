@@ -4588,6 +4588,17 @@ __global__ __launch_bounds__(64 * NW) MGD_VGPR_MFMA void wgrad_skel_kernel(float
       dma_rows_asm<D1, 1024>(vo4, srd, lds_addr(smem) + (wave & 3) * 1024);
       dma_rows_asm<D2, 1024>(vo2, srd, lds_addr(smem) + 16384 + (wave & 3) * 1024);
     }
+    if (MODE & 2048) {                         // six LDS-DMA pieces behind ONE M0 set-up, told apart by the immediate offset
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                   "buffer_load_dwordx4 %3, %2, 0 offen lds\n\tbuffer_load_dwordx4 %3, %2, 0 offen offset:1024 lds\n\t"
+                   "buffer_load_dwordx4 %3, %2, 0 offen offset:2048 lds\n\tbuffer_load_dwordx4 %3, %2, 0 offen offset:3072 lds\n\t"
+                   "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                   "buffer_load_dwordx4 %3, %2, 0 offen lds\n\tbuffer_load_dwordx4 %3, %2, 0 offen offset:1024 lds\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(keep) : "s"(lds_addr(smem) + (wave & 3) * 4096), "s"(srd), "v"(vo4[0]), "s"(lds_addr(smem) + 16384 + (wave & 3) * 2048)
+                   : "memory");
+    }
     if (MODE & 32) {                           // the same six pieces as register loads + ds_write_b128 of the previous step's
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -4693,6 +4704,8 @@ extern "C" int mgd_debug_wgrad_skeleton(float* out, int blocks, int iters, int m
     case 31: launch_skel<31>(out, blocks, iters, st); break;
     case 32: launch_skel<32>(out, blocks, iters, st); break;
     case 35: launch_skel<35>(out, blocks, iters, st); break;
+    case 2048: launch_skel<2048>(out, blocks, iters, st); break;
+    case 2051: launch_skel<2051>(out, blocks, iters, st); break;
     case 43: launch_skel<43>(out, blocks, iters, st); break;
     case 64 + 0: launch_skel<0, 4, 4, 8, 4, 2, 96>(out, blocks, iters, st); break;
     case 64 + 7: launch_skel<7, 4, 4, 8, 4, 2, 96>(out, blocks, iters, st); break;

@@ -31,8 +31,9 @@ names = {0: "bare MFMAs", 1: "+ 24 fragment reads (bursts, lgkmcnt(0))", 9: "+ 2
          3: "reads (bursts) + barrier", 11: "reads (interleaved) + barrier", 7: "reads (bursts) + barrier + LDS-DMA", 15: "reads (interleaved) + barrier + LDS-DMA",
          23: "reads (bursts) + barrier + LDS-DMA + setprio", 31: "reads (interleaved) + barrier + LDS-DMA + setprio",
          32: "+ 6 register loads (out of range) + 6 ds_write_b128", 35: "reads (bursts) + barrier + register loads + ds_write",
-         43: "reads (interleaved) + barrier + register loads + ds_write"}
-for mode in (0, 1, 9, 2, 4, 32, 3, 11, 7, 15, 23, 31, 35, 43):
+         43: "reads (interleaved) + barrier + register loads + ds_write",
+         2048: "+ 6 LDS-DMA behind one M0 set-up per group (immediate offsets)", 2051: "reads (bursts) + barrier + LDS-DMA (immediate offsets)"}
+for mode in (0, 1, 9, 2, 4, 2048, 32, 3, 11, 7, 2051, 15, 23, 31, 35, 43):
     blocks, iters = 768, 4000
     fl = blocks * 4 * iters * 16 * 2.0 * 16 * 16 * 32
     for _ in range(2):
@@ -45,7 +46,7 @@ for mode in (0, 1, 9, 2, 4, 32, 3, 11, 7, 15, 23, 31, 35, 43):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 3
-    print(f"mode {mode:2d} {names[mode]:52s}: {ms:7.3f} ms  {fl / ms / 1e9:7.0f} TFLOP/s", flush=True)
+    print(f"mode {mode:4d} {names[mode]:52s}: {ms:7.3f} ms  {fl / ms / 1e9:7.0f} TFLOP/s", flush=True)
 
 print("candidate tiles (mode bits 7 = reads in bursts + barrier + LDS-DMA, 15 = reads interleaved):")
 shapes = {1: ("256 x 128, 8 waves of 64 x 64, 6 LDS-DMA, one workgroup per CU", 256, 8, 32),
