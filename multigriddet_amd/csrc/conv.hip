@@ -2830,7 +2830,8 @@ __global__ __launch_bounds__(256) MGD_VGPR_MFMA void conv_wgrad4_kernel(WgradArg
       if constexpr (NR == 2) { if (more) fire(BUF ^ 1); }
       else fire((BUF + NR - 1) % NR);        // into the slot every wave left before this barrier (a dummy stage past the end)
     };
-    if (!fire_late) do_fire();
+    const bool fire_mid = a.dbg & 33554432;    // diagnostic: LDS-DMA issue in the shadow of the first fragment reads' latency
+    if (!fire_late && !fire_mid) do_fire();
     if constexpr (KK == 2) {
       s16x4 fa[2][MT][2], fb[2][NT][2];
       auto read_half = [&](int kk) {
@@ -2912,6 +2913,7 @@ __global__ __launch_bounds__(256) MGD_VGPR_MFMA void conv_wgrad4_kernel(WgradArg
         wait_lgkm_dyn(0);
       } else {
       if (!no_reads) read_half(0);
+      if (fire_mid) do_fire();
       wait_lgkm_dyn(0);
       if (!no_reads) read_half(1);          // in flight under the MFMAs of the first half
       mfma_half(0);
