@@ -123,6 +123,9 @@ int mgd_debug_mfma_peak(float* out, int blocks, int iters, int nacc, void* strea
 /* Diagnostic: the weight gradient's K-step rebuilt around that stream, one ingredient per `mode` bit (fragment reads, barrier,
  * LDS-DMA issue, interleaved reads, s_setprio): what each costs next to 16 MFMAs (tools/mfma_peak.py). */
 int mgd_debug_wgrad_skeleton(float* out, int blocks, int iters, int mode, void* stream);
+/* Diagnostic: the same for the gather-GEMM's K-step (ds_read_b128 fragments, weights as register loads or from LDS), by tile
+ * shape (see conv.hip). */
+int mgd_debug_gemm_skeleton(float* out, int blocks, int iters, int shape, void* stream);
 int mgd_latency_workspace(int64_t bytes, void** out, int64_t* capacity);
 int mgd_latency_tickets(unsigned* out4096);
 

@@ -103,7 +103,7 @@ class DecodeCfg(C.Structure):
 
 # every symbol include/mgd_hip.h declares
 EXPORTS = [
-    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_debug_stamps", "mgd_debug_mfma_peak", "mgd_debug_wgrad_skeleton", "mgd_latency_workspace", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_stem_fwd", "mgd_stem_fwd_act", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
+    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_debug_stamps", "mgd_debug_mfma_peak", "mgd_debug_wgrad_skeleton", "mgd_debug_gemm_skeleton", "mgd_latency_workspace", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_stem_fwd", "mgd_stem_fwd_act", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
     "mgd_pack_weights", "mgd_pack_weights_batch", "mgd_stem_im2col", "mgd_bn_finalize", "mgd_bn_act_fwd", "mgd_bn_act_fwd_fused", "mgd_bn_act_bwd_reduce", "mgd_bn_act_bwd_apply",
     "mgd_upsample_concat_fwd", "mgd_upsample_concat_bwd", "mgd_bias_grad", "mgd_f32_to_bf16", "mgd_bf16_to_f32",
     "mgd_adam_step", "mgd_adam_step_dev", "mgd_sgd_step", "mgd_build_targets_workspace_size", "mgd_build_targets",

@@ -4724,6 +4724,116 @@ extern "C" int mgd_debug_wgrad_skeleton(float* out, int blocks, int iters, int m
   return MGD_OK;
 }
 
+// Diagnostic: the gather-GEMM's K-step around the bare MFMA stream.  Per wave and 64-deep step: 2 * MT * NT MFMAs; pixel
+// fragments by ds_read_b128 (2 * NT); weight fragments either as WL register loads (buffer_load_dwordx4, out of range - the form
+// of conv_gemm8_kernel: 2 * MT of them) or by ds_read_b128 from LDS (WL = 0: 2 * MT reads - weights staged by LDS-DMA like the
+// pixels); DX LDS-DMA instructions (out of range); one barrier.  NW waves per workgroup, LKB KiB of LDS (sets workgroups per CU).
+template <int MT, int NT, int NW, int DX, int WL, int LKB>
+__global__ __launch_bounds__(64 * NW) MGD_VGPR_MFMA void gemm_skel_kernel(float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 32 * 1024 / 4; i += 64 * NW) ((unsigned*)smem)[i] = 0x3f803f80u + i;
+  __syncthreads();
+  // conflict-free 16-byte fragment reads: row = lane & 15 (128-byte rows, chunk XOR-swizzled by the row), k-group = lane >> 4
+  const unsigned base = lds_addr(smem) + (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) << 4);
+  i32x4 srd;
+  srd[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)out);
+  srd[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(((unsigned long long)out >> 32) & 0xFFFFu));
+  srd[2] = 0;
+  srd[3] = 0x00020000;
+  unsigned vo[DX > 0 ? DX : 1];
+#pragma unroll
+  for (int i = 0; i < DX; ++i) vo[i] = lane * 16 + i * 64;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 wf[2][MT], xf[NT];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wf[kk][m][i] = (bf16_t)(0x3f80 + lane + i);
+  bf16x8 wn[2][MT];                               // WL: the NEXT step's weight fragments, in flight under this step's MFMAs
+  for (int it = 0; it < iters; ++it) {
+    __builtin_amdgcn_s_barrier();
+    if constexpr (DX > 0) dma_rows_asm<DX, 1024>(vo, srd, lds_addr(smem) + 16384 + (wave & 3) * 1024);
+    if constexpr (WL > 0) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(wn[kk][m]) : "v"(lane * 16u + (unsigned)(kk * MT + m) * 1024u), "s"(srd) : "memory");
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[n]) : "v"(base + (n & 7) * 2048), "n"(0));
+      if constexpr (WL == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[kk][m]) : "v"(base + (m & 7) * 2048), "n"(64));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(xf[n]));
+#pragma unroll
+      for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(wf[kk][m]));
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][m], xf[n], acc[m][n], 0, 0, 0);
+    }
+    if constexpr (WL > 0) {                       // they have had the whole step: wait, then they are the current set
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          asm volatile("" : "+v"(wn[kk][m]));
+          wf[kk][m] = wn[kk][m];
+        }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  f32x4 t = acc[0][0];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) t += acc[m][n];
+  if (t[0] == 123.456f) out[threadIdx.x] = t[1] + t[2] + t[3];
+}
+
+template <int MT, int NT, int NW, int DX, int WL, int LKB>
+static void launch_gemm_skel(float* out, int blocks, int iters, hipStream_t st) {
+  auto k = gemm_skel_kernel<MT, NT, NW, DX, WL, LKB>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * NW), LKB * 1024, st, out, iters);
+}
+
+// shape: 0 = conv_gemm8_kernel's step (4 waves of 32 x 128: MT 2, NT 8, 4 LDS-DMA + 4 register weight loads, 48 KB: three per CU);
+// 1 = the same with the weights read from LDS (4 + 4 LDS-DMA); 2 = 256 x 128 block, 8 waves of 64 x 64, weights from LDS, 2 + 4
+// LDS-DMA per wave, one workgroup per CU; 3 = 256 x 256 block, 8 waves of 128 x 64, weights from LDS, 4 + 4 LDS-DMA, one per CU;
+// 4 = 128 x 256 block, 4 waves of 64 x 128 (MT 4, NT 8), register weights (8) + 8 LDS-DMA, two per CU
+extern "C" int mgd_debug_gemm_skeleton(float* out, int blocks, int iters, int shape, void* stream) {
+  MGD_REQUIRE(out && blocks >= 1 && iters >= 1, "gemm_skeleton: arguments");
+  hipStream_t st = (hipStream_t)stream;
+  switch (shape) {
+    case 0: launch_gemm_skel<2, 8, 4, 4, 1, 48>(out, blocks, iters, st); break;
+    case 1: launch_gemm_skel<2, 8, 4, 6, 0, 48>(out, blocks, iters, st); break;
+    case 2: launch_gemm_skel<4, 4, 8, 6, 0, 100>(out, blocks, iters, st); break;
+    case 3: launch_gemm_skel<8, 4, 8, 6, 0, 130>(out, blocks, iters, st); break;
+    case 4: launch_gemm_skel<4, 8, 4, 6, 1, 70>(out, blocks, iters, st); break;
+    case 5: launch_gemm_skel<2, 8, 4, 0, 0, 48>(out, blocks, iters, st); break;      // reads + barrier only
+    default: MGD_REQUIRE(false, "gemm_skeleton: shape %d not built", shape);
+  }
+  MGD_CHECK_LAUNCH("gemm_skeleton");
+  return MGD_OK;
+}
+
 extern "C" int mgd_debug_mfma_peak(float* out, int blocks, int iters, int nacc, void* stream) {
   MGD_REQUIRE(out && blocks >= 1 && iters >= 1, "mfma_peak: arguments");
   if (nacc == 16) hipLaunchKernelGGL(mfma_peak_kernel<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);

@@ -68,3 +68,25 @@ for shp, (name, blocks, nw, mf) in shapes.items():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
         print(f"{name}, bits {bits:2d}: {ms:7.3f} ms  {fl / ms / 1e9:7.0f} TFLOP/s", flush=True)
+
+print("gather-GEMM K-step skeleton (ds_read_b128 fragments, one barrier per 64-deep step):")
+gshapes = {5: ("128 x 128, 4 waves of 32 x 128: fragment reads + barrier only, three per CU", 768, 4, 32),
+           0: ("128 x 128, 4 waves of 32 x 128, 4 LDS-DMA + 4 register weight loads (conv_gemm8_kernel), three per CU", 768, 4, 32),
+           1: ("128 x 128, 4 waves of 32 x 128, weights from LDS, 6 LDS-DMA, three per CU", 768, 4, 32),
+           2: ("256 x 128, 8 waves of 64 x 64, weights from LDS, 6 LDS-DMA, one per CU", 256, 8, 32),
+           3: ("256 x 256, 8 waves of 128 x 64, weights from LDS, 6 LDS-DMA (of 8), one per CU", 256, 8, 64),
+           4: ("128 x 256, 4 waves of 64 x 128, 8 register weight loads + 6 LDS-DMA (of 8), two per CU", 512, 4, 64)}
+for shp, (name, blocks, nw, mf) in gshapes.items():
+    iters = 3000
+    fl = blocks * nw * iters * mf * 2.0 * 16 * 16 * 32
+    for _ in range(2):
+        L.check(lib.mgd_debug_gemm_skeleton(L.ptr(out), blocks, iters, shp, L.stream_ptr()), "gemm skeleton")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        L.check(lib.mgd_debug_gemm_skeleton(L.ptr(out), blocks, iters, shp, L.stream_ptr()), "gemm skeleton")
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    print(f"{name}: {ms:7.3f} ms  {fl / ms / 1e9:7.0f} TFLOP/s", flush=True)
