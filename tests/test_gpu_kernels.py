@@ -1077,3 +1077,21 @@ def test_per_scale_nms_option_vs_oracle(dev):
         assert differs
     with pytest.raises(ValueError):
         dec.postprocess_batch(heads, shapes, nms_method="soft", per_scale_nms=True)
+
+
+def test_diagnostic_entry_points_run(dev):
+    """mgd_debug_mfma_peak / mgd_debug_wgrad_skeleton / mgd_debug_gemm_skeleton (tools/mfma_peak.py): every built mode
+    launches and completes; unknown modes are refused.  (Their numbers are documentation, not asserted: DESIGN.md section 3.)"""
+    from multigriddet_amd import _lib as L
+    lib = L.load()
+    out = torch.zeros(1024, device=dev)
+    for nacc in (8, 16):
+        L.check(lib.mgd_debug_mfma_peak(L.ptr(out), 64, 10, nacc, L.stream_ptr()), "mfma_peak")
+    for mode in (0, 1, 2, 3, 4, 7, 9, 11, 15, 23, 31, 32, 35, 43, 2048, 2051, 64, 64 + 7, 64 + 15, 128, 128 + 7, 128 + 15, 192,
+                 192 + 7, 192 + 15):
+        L.check(lib.mgd_debug_wgrad_skeleton(L.ptr(out), 32, 5, mode, L.stream_ptr()), f"wgrad skeleton {mode}")
+    for shape in range(6):
+        L.check(lib.mgd_debug_gemm_skeleton(L.ptr(out), 32, 5, shape, L.stream_ptr()), f"gemm skeleton {shape}")
+    torch.cuda.synchronize()
+    assert lib.mgd_debug_wgrad_skeleton(L.ptr(out), 32, 5, 5, L.stream_ptr()) != 0
+    assert lib.mgd_debug_gemm_skeleton(L.ptr(out), 32, 5, 99, L.stream_ptr()) != 0
