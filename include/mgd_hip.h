@@ -37,10 +37,6 @@ int mgd_version(void);
  * measurement code tags its event brackets with it (bench.py).  No reference counterpart. */
 const char* mgd_last_kernel(void);
 
-/* Diagnostic only (tools/stamp_gemm9.py): reads and clears the 3 x 8 phase-time accumulators of the stamped build of the
- * gather-GEMM (MGD_DBG=4096).  No reference counterpart. */
-int mgd_debug_stamps(unsigned long long* out24);
-
 /* ----------------------------------------------------------------------------------------------
  * Convolution engine (implicit GEMM on bf16 MFMA, fp32 accumulate).
  * Replaces: Keras Conv2D as used by DarknetConv2D / DarknetConv2D_BN_Leaky
@@ -91,11 +87,7 @@ typedef struct mgd_conv_desc {
    * act_slope != 0 applies LeakyReLU(act_slope) to (acc + bias) before the optional `addend` (= the residual input),
    * i.e. the whole DarknetConv2D_BN_Leaky (+ Add) of models/layers.py:88-95 in one launch.  bf16 output only. */
   float act_slope;
-  /* Split-K for launches with few output tiles and a long contraction (batch-1 inference on the 19x19 / 38x38 maps: 24-48
-   * tiles of 72 / 36 serial K-steps): splitk > 1 cuts K into `splitk` ranges, every (tile, range) block stores an fp32
-   * partial tile into partial[range][N*Hd*Wd*Co] (plain stores: deterministic), and a second launch adds the ranges, applies
-   * bias / act_slope / addend and writes bf16 `dst`.  bf16 output without stats / bn_y only; partial_bytes >=
-   * splitk * N*Hd*Wd*Co * 4.  0 or 1: off. */
+  /* K ranges of the latency form (below): 0 or 1 = none.  `partial` / `partial_bytes`: its caller-owned workspace. */
   int32_t splitk;
   float* partial;
   int64_t partial_bytes;
@@ -103,31 +95,46 @@ typedef struct mgd_conv_desc {
    * far too small to fill 256 CUs with 128 x 128 tiles): blocks of 128 channels x 64 pixels x one of max(splitk, 1) K
    * ranges, all of a block's K-steps in flight at once, and the ranges added INSIDE the kernel by the last block to arrive
    * at each tile (in range order: deterministic) - no second launch.  With splitk > 1 `partial` is the workspace: 16 KiB of
-   * tile tickets that the caller zero-fills ONCE (launches leave them at zero), then splitk * tiles * 32 KiB of fp32
-   * partial tiles, tiles = Co_pad/128 * ceil(N*Hg*Wg / 64) <= 4096; partial_bytes covers both.  Launches that share a
-   * workspace must be ordered on one stream.  Needs Co_pad % 128 == 0, bf16 output, no stats / bn_y, and ntaps == 1 or
+   * tile tickets that start at zero (launches leave them at zero), then splitk * tiles * 32 KiB of fp32
+   * partial tiles, tiles = Co_pad/128 * ceil(N*Hg*Wg / 64) <= 4096; partial_bytes covers both (mgd_latency_workspace_size).
+   * The workspace must be UNCACHED device memory (mgd_uncached_alloc) owned by the caller; launches that share one must be
+   * ordered on one stream.  Needs Co_pad % 128 == 0, bf16 output, no stats / bn_y, and ntaps == 1 or
    * Ci % 64 == 0; anything else is refused. */
   int32_t latency;
+  /* Kernel form.  0 (MGD_CONV_AUTO): the library chooses from the geometry (measured rules).  Any other
+   * value forces one form and fails with MGD_EINVAL when that form cannot run the geometry - for tests and A/B measurements;
+   * the library reads no environment variables.  form_arg: the form's tile selector (0 = its default). */
+  int32_t form;
+  int32_t form_arg;
 } mgd_conv_desc;
+
+enum {
+  MGD_CONV_AUTO = 0,
+  MGD_CONV_THIN = 2,        /* conv_gemm2_kernel: 64- / 32-channel tiles, both operands in a 2-stage LDS-DMA ring        */
+  MGD_CONV_PRODCONS = 6,    /* conv_gemm6_kernel: 4 loader + 4 MFMA waves, 128 x 128 tiles                                */
+  MGD_CONV_GLOBALW = 8,     /* conv_gemm8_kernel: weight fragments straight from global memory, three blocks per CU      */
+  MGD_CONV_COUNTED = 9,     /* conv_gemm9_kernel, 4 waves; form_arg = pixel tile / 16 (12, 8, 6, 4)                       */
+  MGD_CONV_PINGPONG = 10,   /* conv_gemm9_kernel, 8 waves in two groups; form_arg = pixel tile / 16 (8, 12)               */
+  MGD_CONV_PHASED = 12,     /* conv_gemm12_kernel: 8 waves, counted LDS-DMA across barriers; form_arg: 0 = 256 x 256,     */
+                            /*   1 = 256 x 192, 2 = 128 channels x 384 pixels                                             */
+  MGD_CONV_PATCH = 13       /* conv_patch_kernel (32 -> 64 and 64 -> 32 channel 3x3 layers)                               */
+};
 
 int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream);
 
-/* Workspace for mgd_conv_desc.latency with splitk > 1: uncached device memory owned by the library (one buffer per device,
- * grown on demand, the ticket area zero-filled) - partial tiles written by blocks on one XCD are read by a block on another
- * inside the same kernel, which ordinary (L2-cached) device memory does not guarantee.  *out / *capacity: the buffer and its
- * size (>= bytes).  Synchronises the device when it has to (re)allocate: call it once with the largest size before capturing
- * a stream.  mgd_latency_tickets: test hook, copies the 4096 tickets to the host. */
-/* Diagnostic: `blocks` workgroups of 4 waves each issue iters x nacc (8 or 16) independent v_mfma_f32_16x16x32_bf16 on register
- * operands - the matrix pipe's ceiling at the clock the part holds under that load (tools/mfma_peak.py). */
-int mgd_debug_mfma_peak(float* out, int blocks, int iters, int nacc, void* stream);
-/* Diagnostic: the weight gradient's K-step rebuilt around that stream, one ingredient per `mode` bit (fragment reads, barrier,
- * LDS-DMA issue, interleaved reads, s_setprio): what each costs next to 16 MFMAs (tools/mfma_peak.py). */
-int mgd_debug_wgrad_skeleton(float* out, int blocks, int iters, int mode, void* stream);
-/* Diagnostic: the same for the gather-GEMM's K-step (ds_read_b128 fragments, weights as register loads or from LDS), by tile
- * shape (see conv.hip). */
-int mgd_debug_gemm_skeleton(float* out, int blocks, int iters, int shape, void* stream);
-int mgd_latency_workspace(int64_t bytes, void** out, int64_t* capacity);
-int mgd_latency_tickets(unsigned* out4096);
+/* Workspace of the latency form with K ranges (mgd_conv_desc.latency, splitk > 1).  Partial tiles written by blocks on one
+ * XCD are read by a block on another inside the same kernel, which ordinary (L2-cached) device memory does not guarantee, so
+ * the workspace is UNCACHED device memory - and it is the CALLER's: the library keeps no buffer and no other state, so two
+ * callers (two models, two streams) never share tickets or partial tiles.  One workspace serves the launches of ONE stream.
+ *   mgd_latency_workspace_size(tiles, ranges): bytes for launches of up to `tiles` tiles (128 channels x 64 pixels) x `ranges`;
+ *   mgd_uncached_alloc / mgd_uncached_free: hipExtMallocWithFlags(hipDeviceMallocUncached) on the current device, the first
+ *     16 KiB (the tickets) zero-filled; both synchronise the device - call them outside stream capture;
+ *   mgd_latency_tickets: test hook, waits for `stream` and copies the 4096 tickets to the host (all zero between launches).
+ * No reference counterpart. */
+int64_t mgd_latency_workspace_size(int tiles, int ranges);
+int mgd_uncached_alloc(int64_t bytes, void** out);
+int mgd_uncached_free(void* p);
+int mgd_latency_tickets(const void* workspace, unsigned* out4096, void* stream);
 
 
 /* Stride-2 data gradient of a 3x3 conv with 32 input / 64 output channels (the first down-sampling layer,
@@ -164,7 +171,18 @@ typedef struct mgd_wgrad_desc {
   int32_t in_stride, ntaps;
   int32_t dh[9], dw_off[9];
   int32_t splits;
+  /* Kernel form: 0 = the library's choice from the geometry; otherwise that form or MGD_EINVAL (tests, A/B runs).
+   * form_arg: MGD_WGRAD_DESC - ring depth 2 / 3 / 4 (0 = by layer). */
+  int32_t form;
+  int32_t form_arg;
 } mgd_wgrad_desc;
+
+enum {
+  MGD_WGRAD_AUTO = 0,
+  MGD_WGRAD_PERTAP = 2,   /* conv_wgrad2_kernel: per-tap blocks, carried source coordinates (any stride)            */
+  MGD_WGRAD_PATCH = 3,    /* conv_wgrad3_kernel: all nine taps of a [64 co] x [Ci] slice per block (Ci = 32 / 64)   */
+  MGD_WGRAD_DESC = 4      /* conv_wgrad4_kernel: per-tap blocks, raw buffer descriptors (stride-1 'same' layers)    */
+};
 
 int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream);
 

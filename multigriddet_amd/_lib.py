@@ -9,8 +9,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MGD_LIB_AB: A/B measurements of two builds of the library in one GPU call (tools/ab_lib.sh); never set in product runs
-LIB_PATH = os.environ.get("MGD_LIB_AB") or os.path.join(_HERE, "csrc", "libmgd_hip.so")
+LIB_PATH = os.path.join(_HERE, "csrc", "libmgd_hip.so")
+# the diagnostic build (ablation / stamped instantiations, skeleton kernels; include/mgd_hip_diag.h): tools/ only, see use_diag()
+DIAG_LIB_PATH = os.path.join(_HERE, "csrc", "libmgd_hip_diag.so")
 _lib = None
 
 
@@ -31,6 +32,7 @@ class ConvDesc(C.Structure):
         ("bn_y", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_mean", C.c_void_p),
         ("bn_invstd", C.c_void_p), ("bn_sums", C.c_void_p), ("bn_slope", C.c_float), ("act_slope", C.c_float),
         ("splitk", C.c_int32), ("partial", C.c_void_p), ("partial_bytes", C.c_int64), ("latency", C.c_int32),
+        ("form", C.c_int32), ("form_arg", C.c_int32),
     ]
 
 
@@ -51,7 +53,7 @@ class WgradDesc(C.Structure):
         ("N", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("Ci", C.c_int32),
         ("Hg", C.c_int32), ("Wg", C.c_int32), ("Co", C.c_int32),
         ("in_stride", C.c_int32), ("ntaps", C.c_int32), ("dh", C.c_int32 * 9), ("dw_off", C.c_int32 * 9),
-        ("splits", C.c_int32),
+        ("splits", C.c_int32), ("form", C.c_int32), ("form_arg", C.c_int32),
     ]
 
 
@@ -103,7 +105,7 @@ class DecodeCfg(C.Structure):
 
 # every symbol include/mgd_hip.h declares
 EXPORTS = [
-    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_debug_stamps", "mgd_debug_mfma_peak", "mgd_debug_wgrad_skeleton", "mgd_debug_gemm_skeleton", "mgd_latency_workspace", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_stem_fwd", "mgd_stem_fwd_act", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
+    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_latency_workspace_size", "mgd_uncached_alloc", "mgd_uncached_free", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_stem_fwd", "mgd_stem_fwd_act", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
     "mgd_pack_weights", "mgd_pack_weights_batch", "mgd_stem_im2col", "mgd_bn_finalize", "mgd_bn_act_fwd", "mgd_bn_act_fwd_fused", "mgd_bn_act_bwd_reduce", "mgd_bn_act_bwd_apply",
     "mgd_upsample_concat_fwd", "mgd_upsample_concat_bwd", "mgd_bias_grad", "mgd_f32_to_bf16", "mgd_bf16_to_f32",
     "mgd_adam_step", "mgd_adam_step_dev", "mgd_sgd_step", "mgd_build_targets_workspace_size", "mgd_build_targets",
@@ -114,6 +116,22 @@ EXPORTS = [
     "mgd_conv2d_f32_fwd", "mgd_conv2d_f32_dgrad", "mgd_conv2d_f32_wgrad", "mgd_bn_stats_f32", "mgd_bn_act_fwd_f32",
     "mgd_bn_act_bwd_f32", "mgd_upsample_concat_fwd_f32", "mgd_upsample_concat_bwd_f32", "mgd_bias_grad_f32",
 ]
+
+
+# what libmgd_hip_diag.so exports on top (include/mgd_hip_diag.h)
+DIAG_EXPORTS = ["mgd_diag_set_flags", "mgd_diag_flags_value", "mgd_debug_stamps", "mgd_debug_mfma_peak",
+                "mgd_debug_wgrad_skeleton", "mgd_debug_gemm_skeleton"]
+
+
+def use_diag():
+    """Make this process run on the DIAGNOSTIC library (tools/ only; before the first load()).  It is the same code built with
+    -DMGD_DIAG: kernels with ablation switches and stamps, never what a product run measures or ships."""
+    global LIB_PATH, _lib
+    if _lib is not None and LIB_PATH != DIAG_LIB_PATH:
+        raise MgdError("use_diag() must come before the first use of the library")
+    LIB_PATH = DIAG_LIB_PATH
+    print(f"[multigriddet_amd] DIAGNOSTIC library in use: {DIAG_LIB_PATH}", flush=True)
+    return load()
 
 
 def load():
@@ -132,6 +150,10 @@ def load():
     for name in ("mgd_build_targets_workspace_size", "mgd_loss_workspace_size", "mgd_decode_workspace_size",
                  "mgd_nms_workspace_size", "mgd_wbf_workspace_size", "mgd_letterbox_workspace_size"):
         getattr(lib, name).restype = C.c_size_t
+    lib.mgd_latency_workspace_size.restype = C.c_int64
+    lib.mgd_uncached_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
+    lib.mgd_uncached_free.argtypes = [C.c_void_p]
+    lib.mgd_latency_tickets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 

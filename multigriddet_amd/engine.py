@@ -68,6 +68,7 @@ class Network:
         self.precision = precision
         self.fp32 = precision == "fp32"
         self.O = ops32 if self.fp32 else ops          # the op set forward / backward call
+        self._lat_ws = {}                             # stream handle -> ops.LatencyWorkspace (latency_workspace())
         self.act_dtype = torch.float32 if self.fp32 else torch.bfloat16
         self.device = torch.device(device)
         self.num_classes, self.num_anchors = num_classes, num_anchors
@@ -332,6 +333,18 @@ class Network:
             cv.pk.refresh_fwd(w)
             cv.pk.fwd = keep
 
+    def latency_workspace(self):
+        """This network's workspace of the latency-form convolutions ON THE CURRENT STREAM (ops.LatencyWorkspace: uncached
+        tickets + partial tiles).  One per (network, stream): two models, or one model driven from two streams, never share
+        tickets (no global mutable state, safe to call concurrently on different streams)."""
+        if self.fp32 or not ops.LATENCY:
+            return None
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._lat_ws.get(key)
+        if ws is None:
+            ws = self._lat_ws[key] = ops.LatencyWorkspace(self.device)
+        return ws
+
     def _conv_bn_act(self, A, i, x, residual=None):
         cv = self.layers[i]
         tr = self._bn_training(cv)
@@ -342,7 +355,7 @@ class Network:
                                        out=A["a"][i])
         if getattr(self, "folded", False) and not tr:
             return self.O.conv_fwd(x, cv.pk, out=A["a"][i], bias=self._fold_shift[cv.idx], act_slope=ops.LEAKY_SLOPE,
-                                addend=residual, wimg=self._fold_imgs[cv.idx])
+                                addend=residual, wimg=self._fold_imgs[cv.idx], lat_ws=self.latency_workspace())
         if cv.role == "stem":       # matrix-core stem straight from the fp32 image (no im2col image in the forward pass)
             self.O.stem_fwd(x, cv.w, out=y, stats=cv.stats if tr else None)
         else:

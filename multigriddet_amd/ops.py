@@ -21,14 +21,31 @@ STATS_REPLICAS = 16
 PROFILE = None
 
 
+# Kernel form of the gather-GEMM launches (mgd_conv_desc.form / form_arg; 0 = the library's dispatch).  The library itself
+# reads no environment: tests and tools set these module attributes, MGD_CONV_FORM / MGD_CONV_FORM_ARG pre-set them.
+CONV_FORM = int(os.environ.get("MGD_CONV_FORM", "0"))
+CONV_FORM_ARG = int(os.environ.get("MGD_CONV_FORM_ARG", "0"))
+
+
+CONV_FORM_SOFT = os.environ.get("MGD_CONV_FORM_SOFT", "0") == "1"   # measurement runs: a forced form that cannot run a layer falls back
+
+
+def _gather_gemm(lib, d, what):
+    rc = lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr())
+    if rc == -1 and d.form and CONV_FORM_SOFT:
+        d.form = d.form_arg = 0
+        rc = lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr())
+    L.check(rc, what)
+
+
 def _launch_gemm(d, what):
     lib = L.load()
     if PROFILE is None:
-        L.check(lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), what)
+        _gather_gemm(lib, d, what)
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    L.check(lib.mgd_conv_gather_gemm(C.byref(d), L.stream_ptr()), what)
+    _gather_gemm(lib, d, what)
     e1.record()
     variant = lib.mgd_last_kernel().decode()      # the kernel family the library dispatched this launch to
     PROFILE.append((e0, e1, 2.0 * d.N * d.Hg * d.Wg * d.ntaps * d.Ci * d.Co, variant, what))
@@ -155,6 +172,7 @@ def _desc(src, wpk, dst, N, Hs, Ws, Ci, Hg, Wg, Hd, Wd, Co, in_stride, out_strid
           bias=None, addend=None, stats=None, dst_f32=False, bnred=None, act_slope=0.0):
     d = L.ConvDesc()
     d.act_slope = act_slope
+    d.form, d.form_arg = CONV_FORM, CONV_FORM_ARG
     d.src, d.wpk, d.dst = src.data_ptr(), wpk.data_ptr(), dst.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.addend = addend.data_ptr() if addend is not None else None
@@ -174,9 +192,10 @@ def _desc(src, wpk, dst, N, Hs, Ws, Ci, Hg, Wg, Hd, Wd, Co, in_stride, out_strid
     return d
 
 
-def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False, act_slope=0.0, addend=None, wimg=None):
+def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False, act_slope=0.0, addend=None, wimg=None, lat_ws=None):
     """x: bf16 [N,H,W,Ci] -> [N,Ho,Wo,Co]; 'same' for stride 1, top/left pad + 'valid' for stride 2.
-    act_slope / addend / wimg: BatchNorm-folded inference - LeakyReLU(acc + bias) + residual from pre-scaled weights."""
+    act_slope / addend / wimg: BatchNorm-folded inference - LeakyReLU(acc + bias) + residual from pre-scaled weights.
+    lat_ws: the caller's LatencyWorkspace (one per model and stream); without one the latency form runs without K ranges."""
     N, H, W, Ci = x.shape
     assert Ci == pk.ci and x.dtype == torch.bfloat16
     Ho, Wo = (H // 2, W // 2) if pk.s == 2 else (H, W)
@@ -185,20 +204,15 @@ def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=False, act_slope=0.
     dh, dw = taps_fwd(pk.k)
     d = _desc(x, pk.fwd if wimg is None else wimg, out, N, H, W, Ci, Ho, Wo, Ho, Wo, pk.co, pk.s, 1, (0, 0), dh, dw,
               pk.fwd_kpad, pk.fwd_copad, bias=bias, stats=stats, dst_f32=out_f32, act_slope=act_slope, addend=addend)
-    lat = latency_plan(N * Ho * Wo, pk.fwd_copad, pk.fwd_kpad, len(dh), Ci) if (stats is None and not out_f32 and LATENCY) else 0
+    lat = latency_plan(N * Ho * Wo, pk.fwd_copad, pk.fwd_kpad, len(dh), Ci) if (stats is None and not out_f32 and LATENCY and not d.form) else 0
     if lat:
         # a few thousand pixels (small-batch inference): (tile, K range) blocks with everything in flight, ranges added in-kernel
+        if lat > 1 and lat_ws is None:
+            lat = 1
         d.latency, d.splitk = 1, lat
         if lat > 1:
             tiles = (pk.fwd_copad // 128) * -(-(N * Ho * Wo) // 64)
-            d.partial, d.partial_bytes = _latency_workspace(16384 + lat * tiles * 32768, x.device)
-        _launch_gemm(d, "conv_fwd")
-        return out
-    sp = splitk_factor(N * Ho * Wo, pk.fwd_copad, pk.fwd_kpad) if (stats is None and not out_f32 and SPLITK) else 1
-    if sp > 1:
-        # few output tiles, long contraction (small-batch inference on the 19 x 19 / 38 x 38 maps): K ranges on separate CUs
-        ws = _splitk_workspace(sp * N * Ho * Wo * pk.co * 4, x.device)
-        d.splitk, d.partial, d.partial_bytes = sp, ws.data_ptr(), ws.numel() * 4
+            d.partial, d.partial_bytes = lat_ws.get(tiles, lat)
     _launch_gemm(d, "conv_fwd")
     return out
 
@@ -211,7 +225,6 @@ LAT_TILES = int(os.environ.get("MGD_LAT_TILES", "256"))
 LAT_BLOCKS = int(os.environ.get("MGD_LAT_BLOCKS", "256"))
 LAT_RANGES = int(os.environ.get("MGD_LAT_RANGES", "4"))
 LAT_MIN_STEPS = int(os.environ.get("MGD_LAT_MIN_STEPS", "32"))
-_LATENCY_WS = {}
 
 
 def latency_plan(M, co_pad, k_pad, ntaps, ci):
@@ -226,41 +239,46 @@ def latency_plan(M, co_pad, k_pad, ntaps, ci):
     return max(1, min(nk // 4, LAT_RANGES, LAT_BLOCKS // tiles))
 
 
-def _latency_workspace(nbytes, device):
-    """(pointer, capacity) of the library's uncached workspace on the current device: tickets (zero between launches) +
-    partial tiles, shared by the launches of a stream; sized once for 1024 (tile, range) blocks."""
-    ws = _LATENCY_WS.get(device)
-    if ws is None or ws[1] < nbytes:
-        p, cap = C.c_void_p(), C.c_int64()
-        L.check(L.load().mgd_latency_workspace(max(nbytes, 16384 + 1024 * 32768), C.byref(p), C.byref(cap)), "latency_workspace")
-        ws = _LATENCY_WS[device] = (p.value, cap.value)
-    return ws
+class LatencyWorkspace:
+    """Caller-owned workspace of the latency form's K ranges: uncached device memory (mgd_uncached_alloc) holding the tile
+    tickets (zero between launches) and the fp32 partial tiles.  The library keeps no buffer of its own: every model instance
+    owns one workspace per stream it runs on (engine.Network.latency_workspace), so concurrent forwards never share tickets.
+    Sized for 1024 (tile, range) blocks up front - the largest launch latency_plan() admits - and never re-allocated."""
 
+    BLOCKS = 1024
 
-# opt-in (MGD_SPLITK=1): measured at batch 1, 608 x 608 - the 19 x 19 3x3 launches 43 -> 25 us and the 38 x 38 ones 29.5 -> 25 us
-# (two launches each), the 1x1 ones 16 -> 19 us, the whole forward 1.146 -> 1.170 ms: per-launch fixed costs, not the serial
-# K-loop, set the latency of the 75-launch forward
-SPLITK = os.environ.get("MGD_SPLITK", "0") == "1"
-_SPLITK_WS = {}
+    def __init__(self, device):
+        self.device = torch.device(device)
+        lib = L.load()
+        self.nbytes = int(lib.mgd_latency_workspace_size(self.BLOCKS, 1))
+        p = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(lib.mgd_uncached_alloc(C.c_int64(self.nbytes), C.byref(p)), "uncached_alloc")
+        self.ptr = p.value
 
+    def get(self, tiles, ranges):
+        need = int(L.load().mgd_latency_workspace_size(tiles, ranges))
+        if need > self.nbytes:
+            raise L.MgdError(f"latency workspace: {tiles} tiles x {ranges} ranges need {need} bytes, have {self.nbytes}")
+        return self.ptr, self.nbytes
 
-def splitk_factor(M, co_pad, k_pad):
-    """K ranges for a forward launch: 1 unless the launch has at most 96 tiles of 128 x 128 and at least 16 K-steps; then as
-    many ranges as keep >= 8 K-steps each and about 192 blocks in all (batch 1 at 608 x 608: 512 -> 1024 at 19 x 19 = 24 tiles
-    x 72 steps -> 8 ranges of 9; 256 -> 512 at 38 x 38 = 48 tiles x 36 steps -> 4 ranges of 9)."""
-    if co_pad % 128:
-        return 1
-    tiles, nk = (co_pad // 128) * -(-M // 128), k_pad // 64
-    if tiles > 96 or nk < 16:
-        return 1
-    return max(1, min(8, nk // 8, 192 // tiles))
+    def tickets(self):
+        """Test hook: the 4096 tickets after the current stream has drained."""
+        out = (C.c_uint * 4096)()
+        L.check(L.load().mgd_latency_tickets(C.c_void_p(self.ptr), out, L.stream_ptr()), "latency_tickets")
+        return np.frombuffer(out, dtype=np.uint32).copy()
 
+    def close(self):
+        if getattr(self, "ptr", None):
+            with torch.cuda.device(self.device):
+                L.load().mgd_uncached_free(C.c_void_p(self.ptr))
+            self.ptr = None
 
-def _splitk_workspace(nbytes, device):
-    ws = _SPLITK_WS.get(device)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = _SPLITK_WS[device] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-    return ws
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
@@ -301,10 +319,11 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
     return out
 
 
-import os as _os
-_S2_PATCH = _os.environ.get("MGD_S2_PATCH", "1") != "0"
-_WGRAD_BLOCKS = int(_os.environ.get("MGD_WGRAD_BLOCKS", "0"))      # 0: by tile shape
-_WGRAD_TILE = int(_os.environ.get("MGD_WGRAD_TILE", "1"))         # must match the library (same variable)
+_S2_PATCH = os.environ.get("MGD_S2_PATCH", "1") != "0"
+_WGRAD_BLOCKS = int(os.environ.get("MGD_WGRAD_BLOCKS", "0"))      # 0: by tile shape
+# kernel form of the weight-gradient launches (mgd_wgrad_desc.form / form_arg; 0 = the library's dispatch): tests and tools
+WGRAD_FORM = int(os.environ.get("MGD_WGRAD_FORM", "0"))
+WGRAD_FORM_ARG = int(os.environ.get("MGD_WGRAD_FORM_ARG", "0"))
 
 
 def wgrad_splits(P, co, ci, T, target_blocks=None):
@@ -316,13 +335,13 @@ def wgrad_splits(P, co, ci, T, target_blocks=None):
     bco = 128 if co > 64 else (64 if co > 32 else 32)
     bci = 128 if ci > 64 else (64 if ci > 32 else 32)
     big = co > 64 and ci > 64
-    if big and _WGRAD_TILE:
-        bco, bci = {1: (128, 64), 2: (64, 128), 3: (64, 64), 4: (128, 128)}[_WGRAD_TILE]
+    if big:
+        bco, bci = 128, 64
     tiles = -(-co // bco) * -(-ci // bci) * T
     if target_blocks or T == 1:        # 1x1: ~1 block per CU, measured (short blocks, the epilogue dominates)
         target_blocks = target_blocks or 256
         return max(1, min(int(target_blocks / tiles + 0.5), -(-P // 256)))
-    slots = _WGRAD_BLOCKS if _WGRAD_BLOCKS else (768 if (big and _WGRAD_TILE in (1, 4)) else 1280 if (big and _WGRAD_TILE == 3) else 512)
+    slots = _WGRAD_BLOCKS if _WGRAD_BLOCKS else (768 if big else 512)
     atom = 0.05 * (bco * bci) / (128.0 * 128.0)
     best, best_cost = 1, None
     for sp in range(1, max(1, min(256, P // 256)) + 1):
@@ -347,6 +366,7 @@ def conv_wgrad(x, dy, dw, k, s, splits=None):
     for i, (a, b) in enumerate(zip(dh, dwo)):
         d.dh[i], d.dw_off[i] = a, b
     d.splits = splits if splits is not None else wgrad_splits(N * Ho * Wo, Co, Ci, k * k)
+    d.form, d.form_arg = WGRAD_FORM, WGRAD_FORM_ARG
     if PROFILE is None:
         L.check(L.load().mgd_conv_wgrad(C.byref(d), L.stream_ptr()), "conv_wgrad")
         return dw

@@ -28,7 +28,7 @@ def _f(t):
     return L.ptr(t)
 
 
-def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=True, act_slope=0.0, addend=None, wimg=None):
+def conv_fwd(x, pk, out=None, bias=None, stats=None, out_f32=True, act_slope=0.0, addend=None, wimg=None, lat_ws=None):
     N, H, W, Ci = x.shape
     assert Ci == pk.ci and act_slope == 0.0 and addend is None and wimg is None
     Ho, Wo = (H // 2, W // 2) if pk.s == 2 else (H, W)

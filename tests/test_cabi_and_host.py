@@ -157,3 +157,63 @@ def test_bucket_cut_points_follow_layer_boundaries():
         assert e2 == b and b2 < e2
     assert all(b in offs for _, b, _ in bk)
     assert all(e - b >= 100 for _, b, e in bk[:-1])
+
+
+def test_product_library_reads_no_environment_and_exports_no_diagnostics():
+    """Dispatch of a C-ABI call depends on its arguments only: no getenv anywhere under csrc/, the product library exports no
+    mgd_debug_* / mgd_diag_* symbol and include/mgd_hip.h declares none; the diagnostic twin (libmgd_hip_diag.so,
+    include/mgd_hip_diag.h) exports everything the product does plus its own entry points."""
+    import ctypes as C
+    _lib = _build_if_needed()
+    csrc = os.path.join(ROOT, "multigriddet_amd", "csrc")
+    for dp, _, fs in os.walk(csrc):
+        for f in fs:
+            if f.endswith((".hip", ".cpp", ".hpp", ".h")):
+                assert "getenv" not in open(os.path.join(dp, f)).read(), f
+    hdr = open(os.path.join(ROOT, "include", "mgd_hip.h")).read()
+    assert "mgd_debug" not in hdr and "mgd_diag" not in hdr
+    lib = _lib.load()
+    for s in _lib.DIAG_EXPORTS:
+        assert not hasattr(lib, s), s
+    diag = C.CDLL(_lib.DIAG_LIB_PATH)
+    for s in _lib.EXPORTS + _lib.DIAG_EXPORTS:
+        assert hasattr(diag, s), s
+    dh = open(os.path.join(ROOT, "include", "mgd_hip_diag.h")).read()
+    assert sorted(set(re.findall(r"\b(mgd_[a-z0-9_]+)\s*\(", dh))) == sorted(_lib.DIAG_EXPORTS)
+
+
+def test_forced_kernel_forms_are_validated_on_the_host():
+    """mgd_conv_desc.form / mgd_wgrad_desc.form: a form that cannot run the geometry is refused with MGD_EINVAL and a message,
+    never silently replaced (include/mgd_hip.h)."""
+    import ctypes as C
+    _lib = _build_if_needed()
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    fake = 0x10000                                   # never dereferenced: validation fails first
+    d.src, d.wpk, d.dst = fake, fake, fake
+    d.N, d.Hs, d.Ws, d.Ci = 1, 8, 8, 32
+    d.Hg, d.Wg, d.Hd, d.Wd, d.Co = 8, 8, 8, 8, 64
+    d.in_stride, d.out_stride, d.ntaps = 1, 1, 1
+    d.K_pad, d.Co_pad = 64, 64
+    for form, msg in ((12, b"thin-tile"), (10, b"thin-tile"), (6, b"thin-tile"), (77, b"thin-tile")):
+        d.form = form
+        assert lib.mgd_conv_gather_gemm(C.byref(d), None) == -1 and msg in lib.mgd_last_error(), (form, lib.mgd_last_error())
+    d.Co, d.Co_pad, d.form, d.form_arg = 128, 128, 12, 0        # 256-channel tiles on a 128-channel image
+    assert lib.mgd_conv_gather_gemm(C.byref(d), None) == -1 and b"phased" in lib.mgd_last_error()
+    d.form, d.form_arg = 9, 5
+    d.ntaps, d.Ci, d.K_pad = 9, 64, 576
+    for t in range(9):
+        d.dh[t], d.dw[t] = t // 3 - 1, t % 3 - 1
+    assert lib.mgd_conv_gather_gemm(C.byref(d), None) == -1 and b"pixel tile" in lib.mgd_last_error()
+    d.form, d.form_arg, d.splitk = 0, 0, 4           # K ranges without the latency form
+    assert lib.mgd_conv_gather_gemm(C.byref(d), None) == -1 and b"latency" in lib.mgd_last_error()
+    w = _lib.WgradDesc()
+    w.src, w.dy, w.dw = fake, fake, fake
+    w.N, w.Hs, w.Ws, w.Ci, w.Hg, w.Wg, w.Co = 1, 16, 16, 64, 8, 8, 128
+    w.in_stride, w.ntaps, w.splits = 2, 9, 1
+    for t in range(9):
+        w.dh[t], w.dw_off[t] = t // 3 - 1, t % 3 - 1
+    w.form = 4                                       # descriptor form on a stride-2 layer
+    assert lib.mgd_conv_wgrad(C.byref(w), None) == -1 and b"descriptor-addressed" in lib.mgd_last_error()
+    w.form = 9
+    assert lib.mgd_conv_wgrad(C.byref(w), None) == -1 and b"unknown kernel form" in lib.mgd_last_error()

@@ -1,7 +1,9 @@
-"""GPU: parity of every gather-GEMM kernel form built in round 3, each forced through the library's switches in a process
-of its own (the switches are read once per process): the counted-pipeline kernel with 4 and 8 waves, its ping-pong form
-with 128- and 192-pixel tiles, the streaming ping-pong kernel, and the default dispatch - forward with statistics, folded
-inference epilogue and data gradient with addend against fp32 torch (tests/gemm_variant_check.py)."""
+"""GPU: parity of every gather-GEMM kernel form, each forced through mgd_conv_desc.form / form_arg (the library reads no
+environment) in a process of its own: the thin-tile, producer/consumer and global-weight forms, the counted-pipeline kernel
+with 4 waves at three pixel tiles, its ping-pong form with 128- and 192-pixel tiles, the phased 8-wave kernel of round 4 in
+its three tile shapes, and the library's own dispatch - forward with statistics, folded inference epilogue and data gradient
+with addend + fused BatchNorm-backward sums against fp32 torch (tests/gemm_form_check.py).  A geometry the forced form
+refuses (MGD_EINVAL) is repeated under the library's dispatch and reported; the form must have run at least once."""
 import os
 import subprocess
 import sys
@@ -11,23 +13,27 @@ import pytest
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-VARIANTS = [
-    ("default dispatch", {}, "conv_gather_gemm"),
-    ("counted pipeline, 4 waves", {"MGD_GEMM9": "1", "MGD_GEMM9_WC": "4"}, "counted pipeline"),
-    ("counted pipeline, 8 waves, 192 pixels", {"MGD_GEMM9": "1", "MGD_GEMM9_WC": "8", "MGD_GEMM9_NT": "12"}, "counted pipeline"),
-    ("ping-pong, 128 pixels", {"MGD_GEMM9": "1", "MGD_GEMM9_WC": "8", "MGD_GEMM9_NT": "8", "MGD_GEMM9_PP": "1"}, "ping-pong"),
-    ("ping-pong, 192 pixels", {"MGD_GEMM9": "1", "MGD_GEMM9_WC": "8", "MGD_GEMM9_NT": "12", "MGD_GEMM9_PP": "1"}, "ping-pong"),
-    ("streaming ping-pong", {"MGD_GEMM10": "1"}, "streaming ping-pong"),
-    ("round-2 kernel only", {"MGD_GEMM9": "0", "MGD_GEMM8_UNI": "0"}, "global weight fragments"),
+FORMS = [  # name, form, form_arg, expected kernel family
+    ("library dispatch", 0, 0, "conv_gather_gemm"),
+    ("producer / consumer", 6, 0, "producer/consumer"),
+    ("global weight fragments, wave-uniform taps", 8, 0, "global weight fragments"),
+    ("global weight fragments, per-lane taps (round 2)", 8, 1, "global weight fragments"),
+    ("counted pipeline, 4 waves, cost-model tile", 9, 0, "counted pipeline"),
+    ("counted pipeline, 4 waves, 192 pixels", 9, 12, "counted pipeline"),
+    ("counted pipeline, 4 waves, 64 pixels", 9, 4, "counted pipeline"),
+    ("ping-pong, 128 pixels", 10, 8, "ping-pong"),
+    ("ping-pong, 192 pixels", 10, 12, "ping-pong"),
+    ("phased 8 waves, 256 x 256", 12, 0, "phased"),
+    ("phased 8 waves, 256 x 192", 12, 1, "phased"),
+    ("phased 8 waves, 128 x 384", 12, 2, "phased"),
 ]
 
 
-@pytest.mark.parametrize("name,env,expect", VARIANTS, ids=[v[0] for v in VARIANTS])
-def test_gather_gemm_variant_parity(name, env, expect):
+@pytest.mark.parametrize("name,form,arg,expect", FORMS, ids=[f[0] for f in FORMS])
+def test_gather_gemm_form_parity(name, form, arg, expect):
     e = dict(os.environ)
-    for k in ("MGD_GEMM9", "MGD_GEMM9_WC", "MGD_GEMM9_NT", "MGD_GEMM9_PP", "MGD_GEMM10", "MGD_GEMM8_UNI", "MGD_DBG"):
+    for k in ("MGD_CONV_FORM", "MGD_CONV_FORM_ARG", "MGD_CONV_FORM_SOFT"):
         e.pop(k, None)
-    e.update(env)
-    out = subprocess.run([sys.executable, os.path.join(HERE, "gemm_variant_check.py"), expect], env=e, capture_output=True,
-                         text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "gemm_form_check.py"), str(form), str(arg), expect], env=e,
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, f"{name}:\n{out.stdout[-3000:]}\n{out.stderr[-2000:]}"

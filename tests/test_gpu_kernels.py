@@ -49,16 +49,16 @@ CONV_CASES = [
     (1, 10, 10, 320, 64, 1, 1),
     (1, 38, 38, 64, 176, 3, 1),
     (2, 12, 12, 512, 1024, 3, 2),
-    (8, 96, 96, 64, 128, 3, 1),          # enough tiles for the 8-wave / 256-pixel-tile variant
+    (8, 96, 96, 64, 128, 3, 1),          # 576 tiles of 128 x 128: conv_gemm8_kernel over several rounds of block slots
     (4, 128, 128, 32, 64, 3, 2),
     (6, 100, 100, 128, 64, 1, 1),
     (2, 40, 36, 32, 64, 3, 1),           # patch-form weight gradient: Ci = 32, ragged tiles
     (2, 44, 40, 64, 128, 3, 2),          # patch-form weight gradient: Ci = 64, stride 2, ragged tiles
-    (2, 76, 76, 128, 256, 3, 1),         # kernel-row weight gradient (Ci >= 128): full tiles
-    (2, 21, 37, 256, 128, 3, 1),         # kernel-row weight gradient: non-square, ragged tiles, two Ci slices
-    (2, 19, 19, 512, 1024, 3, 1),        # resident-patch gather-GEMM: two passes of 4 chunks (dgrad: four), 4x4 n-tiles
-    (3, 5, 7, 64, 128, 3, 1),            # resident-patch gather-GEMM: map smaller than one tile, three images in it
-    (2, 38, 38, 256, 512, 3, 1),         # resident-patch gather-GEMM: 2x8 n-tiles, tiles spanning the image boundary
+    (2, 76, 76, 128, 256, 3, 1),         # conv_gemm8_kernel (wave-uniform taps) fwd / dgrad; conv_wgrad4_kernel 128 x 64 tiles, 2-stage ring
+    (2, 21, 37, 256, 128, 3, 1),         # producer/consumer form (<= 256 tiles); conv_wgrad4_kernel: non-square map, ragged pixel ranges, two Ci tiles
+    (2, 19, 19, 512, 1024, 3, 1),        # producer/consumer form, 72 / 144 K-steps; conv_wgrad4_kernel with eight Co tiles
+    (3, 5, 7, 64, 128, 3, 1),            # map smaller than one tile, three images in it (conv_gemm8_kernel; patch-form conv_wgrad3 refused: too few pixels -> conv_wgrad4)
+    (2, 38, 38, 256, 512, 3, 1),         # producer/consumer form: tiles spanning the image boundary; 36 / 72 K-steps
 ]
 
 
@@ -162,32 +162,34 @@ def test_stem(dev):
     np.testing.assert_allclose(dw.cpu().numpy() - 0.5, wr2.grad.numpy(), rtol=1e-3, atol=2e-3)
 
 
-def test_wgrad_kernel_row_form_opt_in():
-    """MGD_WGRAD_ROW=1 (read once per process, hence a child process): the kernel-row patch form of the weight
-    gradient for 3x3 stride-1 convs with Ci a multiple of 128 against torch autograd on the same bf16 inputs -
-    ragged tiles, ragged Co, two Ci slices."""
-    import subprocess, sys, os, textwrap
-    code = textwrap.dedent("""
-        import torch, torch.nn.functional as F
-        from multigriddet_amd import ops
-        torch.manual_seed(0)
-        for (N, H, W, Ci, Co) in ((2, 76, 76, 128, 256), (2, 21, 37, 256, 128), (1, 19, 19, 256, 704), (3, 38, 38, 128, 352)):
-            x = torch.randn(N, H, W, Ci).to(torch.bfloat16)
-            dy = torch.randn(N, H, W, Co).to(torch.bfloat16)
-            w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
-            F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=1).backward(dy.float().permute(0, 3, 1, 2))
-            ref = w.grad.permute(0, 2, 3, 1).reshape(Co, 9, Ci)
-            dw = torch.full((Co, 9, Ci), 0.5, device="cuda")
-            ops.conv_wgrad(x.cuda(), dy.cuda(), dw, 3, 1)
-            torch.cuda.synchronize()
-            err = (dw.cpu() - 0.5 - ref).abs().max().item()
-            assert err <= 2e-3 * ref.abs().max().item() + 1e-3, (N, H, W, Ci, Co, err)
-        print("ROW_OK")
-    """)
-    env = dict(os.environ, MGD_WGRAD_ROW="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "ROW_OK" in r.stdout, r.stdout + r.stderr
+@pytest.mark.parametrize("form,arg,expect", [(2, 0, b"conv_wgrad"), (4, 0, b"conv_wgrad(descriptor-addressed)"),
+                                             (4, 3, b"conv_wgrad(descriptor-addressed)"), (4, 4, b"conv_wgrad(descriptor-addressed)")])
+def test_wgrad_forced_forms(dev, form, arg, expect, monkeypatch):
+    """mgd_wgrad_desc.form / form_arg: every weight-gradient kernel form forced through the descriptor (the library reads no
+    environment) against torch autograd on the same bf16 inputs - ragged pixel ranges, ragged Co, two Ci tiles; a form that
+    cannot run a geometry is refused with MGD_EINVAL."""
+    import torch.nn.functional as F
+    from multigriddet_amd import ops
+    monkeypatch.setattr(ops, "WGRAD_FORM", form)
+    monkeypatch.setattr(ops, "WGRAD_FORM_ARG", arg)
+    torch.manual_seed(0)
+    for (N, H, W, Ci, Co) in ((2, 76, 76, 128, 256), (2, 21, 37, 256, 128), (1, 19, 19, 256, 704), (3, 38, 38, 128, 352)):
+        x = torch.randn(N, H, W, Ci).to(torch.bfloat16)
+        dy = torch.randn(N, H, W, Co).to(torch.bfloat16)
+        w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+        F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+        ref = w.grad.permute(0, 2, 3, 1).reshape(Co, 9, Ci)
+        dw = torch.full((Co, 9, Ci), 0.5, device=dev)
+        ops.conv_wgrad(x.to(dev), dy.to(dev), dw, 3, 1)
+        assert ops.L.load().mgd_last_kernel() == expect
+        torch.cuda.synchronize()
+        err = (dw.cpu() - 0.5 - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item() + 1e-3, (N, H, W, Ci, Co, err)
+    if form == 4:                                      # stride 2 is not a 'same' layer: the descriptor form refuses it
+        x = torch.randn(1, 16, 16, 64).to(torch.bfloat16).to(dev)
+        dy = torch.randn(1, 8, 8, 128).to(torch.bfloat16).to(dev)
+        with pytest.raises(ops.L.MgdError):
+            ops.conv_wgrad(x, dy, torch.zeros(128, 9, 64, device=dev), 3, 2)
 
 
 @pytest.mark.parametrize("N,H,W", [(2, 40, 48), (1, 37, 70), (3, 64, 130)])
@@ -303,46 +305,6 @@ def test_conv_bias_leaky_residual_epilogue(dev, N, H, W, Ci, Co, k, s):
     assert err <= 0.02 * ref.abs().max().item() + 1e-3, err
 
 
-@pytest.mark.parametrize("N,H,W,Ci,Co,k,s,splits", [(1, 19, 19, 512, 1024, 3, 1, 8), (1, 38, 38, 256, 512, 3, 1, 4),
-                                                    (2, 19, 19, 1024, 512, 1, 1, 2), (1, 13, 11, 256, 384, 3, 1, 4),
-                                                    (1, 38, 38, 512, 1024, 3, 2, 8)])
-def test_conv_split_k_matches_reference(dev, N, H, W, Ci, Co, k, s, splits):
-    """Split-K route of the forward convolution (few output tiles, long contraction: small-batch inference): K ranges on
-    separate blocks, fp32 partial slabs, a finalize launch with bias + LeakyReLU + residual.  ops.splitk_factor picks the
-    stated number of ranges at these shapes; the result equals the fp32 torch reference within the bf16 output rounding and
-    the single-launch route within one bf16 ulp of the larger operand scale (only the summation order differs); two calls
-    are bit-identical (plain stores, no atomics)."""
-    from multigriddet_amd import ops
-    g = torch.Generator().manual_seed(777 + Ci + Co + H)
-    x = bf(torch.randn(N, H, W, Ci, generator=g))
-    w = torch.randn(Co, k * k, Ci, generator=g) / (k * (Ci ** 0.5))
-    bias = torch.randn(Co, generator=g) * 0.5
-    pk = ops.PackedConv(Co, Ci, k, s, dev)
-    pk.refresh(w.to(dev))
-    Ho, Wo = (H // 2, W // 2) if s == 2 else (H, W)
-    assert ops.splitk_factor(N * Ho * Wo, pk.fwd_copad, pk.fwd_kpad) == splits
-    y_ref = _ref_conv(x, w, k, s) + bias
-    res = bf(torch.randn(*y_ref.shape, generator=g))
-    ref = torch.where(y_ref > 0, y_ref, 0.1 * y_ref) + res.float()
-    xd, bd, rd = x.to(dev), bias.to(dev), res.to(dev)
-    was, was_lat = ops.SPLITK, ops.LATENCY
-    ops.SPLITK = True                                  # opt-in route (MGD_SPLITK=1)
-    ops.LATENCY = False                                # (the default route for shapes this small, tested below)
-    try:
-        out = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
-        assert ops.L.load().mgd_last_kernel() == b"conv_gather_gemm(split-K)"
-        out2 = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
-        ops.SPLITK = False
-        single = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
-    finally:
-        ops.SPLITK, ops.LATENCY = was, was_lat
-    torch.cuda.synchronize()
-    assert torch.equal(out, out2)
-    tol = 0.02 * ref.abs().max().item() + 1e-3
-    assert (out.float().cpu() - ref).abs().max().item() <= tol
-    assert (out.float() - single.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
-
-
 @pytest.mark.parametrize("N,H,W,Ci,Co,k,s,cap,ranges", [(1, 19, 19, 512, 1024, 3, 1, 4, 4), (1, 38, 38, 256, 512, 3, 1, 4, 2),
                                                         (1, 76, 76, 128, 256, 3, 1, 4, 1), (1, 19, 19, 1024, 512, 1, 1, 4, 1),
                                                         (2, 38, 38, 512, 256, 1, 1, 4, 1), (1, 76, 76, 256, 128, 1, 1, 4, 1),
@@ -370,16 +332,19 @@ def test_conv_latency_form_matches_reference(dev, N, H, W, Ci, Co, k, s, cap, ra
     res = bf(torch.randn(*y_ref.shape, generator=g))
     ref = torch.where(y_ref > 0, y_ref, 0.1 * y_ref) + res.float()
     xd, bd, rd = x.to(dev), bias.to(dev), res.to(dev)
+    ws = ops.LatencyWorkspace(dev)                     # caller-owned (the library keeps no workspace): this test's own
     outs = []
     for _ in range(3):
-        outs.append(ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd))
+        outs.append(ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd, lat_ws=ws))
         assert ops.L.load().mgd_last_kernel() == b"conv_gather_gemm(latency form)"
-    plain = ops.conv_fwd(xd, pk)                       # no bias / activation / residual
+    plain = ops.conv_fwd(xd, pk, lat_ws=ws)            # no bias / activation / residual
     # other operands through the same workspace right behind: a partial tile read stale (from the previous launch, out of
     # another XCD's cache) would reproduce the OLD sums
     x2 = bf(torch.randn(N, H, W, Ci, generator=g))
-    other = ops.conv_fwd(x2.to(dev), pk)
-    again = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)
+    other = ops.conv_fwd(x2.to(dev), pk, lat_ws=ws)
+    again = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd, lat_ws=ws)
+    noranges = ops.conv_fwd(xd, pk, bias=bd, act_slope=0.1, addend=rd)          # without a workspace: the form without K ranges
+    assert ops.L.load().mgd_last_kernel() == b"conv_gather_gemm(latency form)"
     y2_ref = _ref_conv(x2, w, k, s)
     ops.LATENCY = False
     try:
@@ -395,11 +360,9 @@ def test_conv_latency_form_matches_reference(dev, N, H, W, Ci, Co, k, s, cap, ra
     assert (other.float().cpu() - y2_ref).abs().max().item() <= 0.02 * y2_ref.abs().max().item() + 1e-3
     assert torch.equal(again, outs[0])
     assert (outs[0].float() - regular.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
-    if ranges > 1:
-        import ctypes as Ct
-        tickets = (Ct.c_uint32 * 4096)()
-        ops.L.check(ops.L.load().mgd_latency_tickets(tickets), "latency_tickets")
-        assert not any(tickets)                                                  # left at zero
+    assert (noranges.float() - outs[0].float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    assert not ws.tickets().any()                                                # left at zero
+    ws.close()
 
 
 @pytest.mark.parametrize("N,H,W,Ci,Co,k,s", [(2, 20, 20, 64, 128, 3, 1), (2, 24, 24, 32, 64, 3, 2), (3, 19, 19, 256, 128, 1, 1),
@@ -1079,19 +1042,33 @@ def test_per_scale_nms_option_vs_oracle(dev):
         dec.postprocess_batch(heads, shapes, nms_method="soft", per_scale_nms=True)
 
 
-def test_diagnostic_entry_points_run(dev):
-    """mgd_debug_mfma_peak / mgd_debug_wgrad_skeleton / mgd_debug_gemm_skeleton (tools/mfma_peak.py): every built mode
-    launches and completes; unknown modes are refused.  (Their numbers are documentation, not asserted: DESIGN.md section 3.)"""
-    from multigriddet_amd import _lib as L
-    lib = L.load()
-    out = torch.zeros(1024, device=dev)
-    for nacc in (8, 16):
-        L.check(lib.mgd_debug_mfma_peak(L.ptr(out), 64, 10, nacc, L.stream_ptr()), "mfma_peak")
-    for mode in (0, 1, 2, 3, 4, 7, 9, 11, 15, 23, 31, 32, 35, 43, 2048, 2051, 64, 64 + 7, 64 + 15, 128, 128 + 7, 128 + 15, 192,
-                 192 + 7, 192 + 15):
-        L.check(lib.mgd_debug_wgrad_skeleton(L.ptr(out), 32, 5, mode, L.stream_ptr()), f"wgrad skeleton {mode}")
-    for shape in range(6):
-        L.check(lib.mgd_debug_gemm_skeleton(L.ptr(out), 32, 5, shape, L.stream_ptr()), f"gemm skeleton {shape}")
-    torch.cuda.synchronize()
-    assert lib.mgd_debug_wgrad_skeleton(L.ptr(out), 32, 5, 5, L.stream_ptr()) != 0
-    assert lib.mgd_debug_gemm_skeleton(L.ptr(out), 32, 5, 99, L.stream_ptr()) != 0
+def test_diagnostic_library_entry_points_run():
+    """libmgd_hip_diag.so (include/mgd_hip_diag.h; tools/mfma_peak.py): mgd_debug_mfma_peak / mgd_debug_wgrad_skeleton /
+    mgd_debug_gemm_skeleton launch and complete in every built mode, unknown modes are refused, and the flag word round-trips.
+    Runs in a child process: the diagnostic library replaces the product library for a whole process (_lib.use_diag).
+    (The numbers are documentation, not asserted: DESIGN.md section 3.)"""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import torch
+        from multigriddet_amd import _lib as L
+        lib = L.use_diag()
+        assert all(hasattr(lib, s) for s in L.EXPORTS + L.DIAG_EXPORTS)
+        out = torch.zeros(1024, device="cuda")
+        for nacc in (8, 16):
+            L.check(lib.mgd_debug_mfma_peak(L.ptr(out), 64, 10, nacc, L.stream_ptr()), "mfma_peak")
+        for mode in (0, 1, 2, 3, 4, 7, 9, 11, 15, 23, 31, 32, 35, 43, 2048, 2051, 64, 64 + 7, 64 + 15, 128, 128 + 7, 128 + 15, 192,
+                     192 + 7, 192 + 15):
+            L.check(lib.mgd_debug_wgrad_skeleton(L.ptr(out), 32, 5, mode, L.stream_ptr()), f"wgrad skeleton {mode}")
+        for shape in range(6):
+            L.check(lib.mgd_debug_gemm_skeleton(L.ptr(out), 32, 5, shape, L.stream_ptr()), f"gemm skeleton {shape}")
+        torch.cuda.synchronize()
+        assert lib.mgd_debug_wgrad_skeleton(L.ptr(out), 32, 5, 5, L.stream_ptr()) != 0
+        assert lib.mgd_debug_gemm_skeleton(L.ptr(out), 32, 5, 99, L.stream_ptr()) != 0
+        lib.mgd_diag_set_flags(48)
+        assert lib.mgd_diag_flags_value() == 48
+        lib.mgd_diag_set_flags(0)
+        print("DIAG_OK")
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIAG_OK" in r.stdout, r.stdout + r.stderr

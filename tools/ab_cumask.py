@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Does confining the weight-gradient side stream to a subset of the CUs (hipExtStreamCreateWithCUMask) shorten the step?
 The side stream's long-running blocks delay the short kernels of the critical chain (BatchNorm passes of the small
 layers run 5-6x their solo time inside the step); a masked side stream always leaves CUs free for them."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Does running the main chain on a high-priority stream (weight gradients stay on a default-priority side stream) help?"""
 import os, statistics, sys, time
 import torch

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Interleaved A/B of engine switches on the benchmark train step (one process, same device, median of rounds).
 usage: python tools/ab_step.py attr=v1,v2 [attr2=...]   e.g.  fuse_bn_reduce=0,1 overlap_wgrad=0,1 ts.use_graph=0,1
 (plain names are attributes of the Network, ts.* of the TrainStep)"""

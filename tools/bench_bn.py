@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Micro-benchmark of the BN/activation elementwise kernels at the benchmark shapes (608x608, batch 16):
 us and algorithmic HBM GB/s per (P, C).  Usage: python tools/bench_bn.py"""
 import os, sys

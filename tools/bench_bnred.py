@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dgrad with / without the fused BN-backward reduction vs the stand-alone reduce pass, per layer shape."""
 import os, sys
 import torch

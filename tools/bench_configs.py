@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """The BASELINE.json configs that are not bench.py's headline line, on one GPU:
   config 1: Darknet53 416x416, single image, forward + decode + DIoU-NMS (latency, ms)
   config 3: multi-scale training, S cycled over {320, ..., 608} per step at batch 16 (images/s over two full cycles)

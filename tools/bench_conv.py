@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-layer micro-benchmark of the conv engine at the benchmark shapes (608x608, batch 16):
 forward gather-GEMM, data-gradient and weight-gradient for every distinct conv of the graph, timed with
 HIP events on the launch stream.  Prints one line per (layer shape, pass) with us, TFLOP/s and the

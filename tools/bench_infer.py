@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Inference throughput incl. decode + NMS (BASELINE metric, second half): images/s of forward (moving BN statistics)
 + batched decode + DIoU-NMS on synthetic 608x608 batches resident in HBM.  One JSON line.
 usage: python tools/bench_infer.py [--batch 16] [--size 608] [--steps 30] [--method diou|soft|cluster|wbf]"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Stem conv (3 -> 32, 608x608, batch 16): direct fp32 kernel vs bf16 im2col + 1x1 GEMM (forward and weight gradient)."""
 import os, sys
 import torch

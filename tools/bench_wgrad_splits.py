@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Split-K sweep of the weight-gradient kernel for one layer shape: python tools/bench_wgrad_splits.py cin cout k s H"""
 import os, sys
 import torch

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Host-side enqueue time of the train step's phases (no device sync inside): is the step launch-bound?"""
 import os, sys, time
 import torch

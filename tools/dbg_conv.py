@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Debug helper: forward conv (3x3, stride 1) against torch fp32 on several shapes; prints where errors sit."""
 import os, sys
 import torch, torch.nn.functional as F

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-launch times of the gather-GEMM launches of ONE folded inference forward (HIP events around every launch; they add
 a few microseconds of gap each, so the sum is above the un-instrumented forward).  usage: infer_layers.py [batch] [size]"""
 import os, sys

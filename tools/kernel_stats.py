@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Condenses rocprofv3's per-kernel statistics (--kernel-trace --stats --output-format csv) into the table committed under
 profiles/: one row per kernel with ms per step, share, launches per step and the average launch duration.
 

@@ -1,5 +1,4 @@
-#!/usr/bin/env python3
-"""The matrix pipe's ceiling on this box: a bare v_mfma_f32_16x16x32_bf16 stream (mgd_debug_mfma_peak: register operands,
+"""(DIAGNOSTIC library, libmgd_hip_diag.so.)  The matrix pipe's ceiling on this box: a bare v_mfma_f32_16x16x32_bf16 stream (mgd_debug_mfma_peak: register operands,
 8 or 16 independent accumulators per wave, no memory traffic) at 1 - 4 workgroups of 4 waves per CU, timed with HIP events.
 Prints TFLOP/s = launches' MFMA FLOPs / time; 2 500 would be the dense bf16 figure at 2.4 GHz."""
 import os, sys
@@ -7,7 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multigriddet_amd import _lib as L
 
-lib = L.load()
+lib = L.use_diag()
 dev = torch.device("cuda:0")
 out = torch.zeros(1024, device=dev)
 for nacc in (8, 16):

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-kernel MFMA utilisation from one rocprofv3 counter pass (MI355X_MICROARCH.md recipe):
 
   cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Run ONE conv shape repeatedly (for rocprofv3 --pmc passes).  usage: one_conv.py cin cout k s H [B] [mode] [iters]"""
 import os, sys
 import torch

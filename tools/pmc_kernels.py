@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-kernel averages of arbitrary rocprofv3 counters, one directory per counter pass:
 
   cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-kernel HBM traffic from two separate rocprofv3 counter passes (the MI355X_MICROARCH.md recipe):
 
   cd /tmp && export TMPDIR=/tmp

@@ -1,12 +1,14 @@
-#!/usr/bin/env python3
-"""Phase times of the ping-pong gather-GEMM (stamped diagnostic build): run with
-   MGD_GEMM9=1 MGD_GEMM9_WC=8 MGD_GEMM9_NT=8 MGD_GEMM9_PP=4 MGD_DBG=4096 python tools/stamp_gemm9.py cin cout k H [B]
+"""Phase times of the ping-pong gather-GEMM (stamped instantiation of the DIAGNOSTIC library, flag 4096):
+   python3 tools/stamp_gemm9.py cin cout k H [B]
 Prints, for waves 0-3 (group A) and 4-7 (group B), the mean s_memtime ticks per K-step spent in each segment."""
 import ctypes as C
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from multigriddet_amd import ops, _lib
+from multigriddet_amd import _lib
+_lib.use_diag().mgd_diag_set_flags(4096)
+from multigriddet_amd import ops
+ops.CONV_FORM, ops.CONV_FORM_ARG = 10, 8      # ping-pong form, 128-pixel tiles
 
 ci, co, k, h = (int(v) for v in sys.argv[1:5])
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 16

@@ -1,7 +1,9 @@
-#!/usr/bin/env python3
 """Timeline of ONE steady-state folded inference forward from a rocprofv3 kernel trace: per launch the kernel's duration and
 the idle gap in front of it.  Two modes:
-  trace_timeline.py run [batch] [graph]      the traced program (forwards only; run it under rocprofv3 --kernel-trace)
+  trace_timeline.py run [batch] [graph]      the traced program (forwards only).  Run it as the profiler's direct child -
+                                             cd /tmp && export TMPDIR=/tmp &&
+                                             rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $REPO/tools/trace_timeline.py run 1
+                                             (never through env / bash -c / a #! script: the profiler has initialised the GPU)
   trace_timeline.py show <dir> [launches]    parse <dir>/**/*kernel_trace.csv, print the last forward's launches"""
 import csv, glob, os, sys
 
