@@ -187,18 +187,43 @@ def per_layer_bench(dev, size, batch, iters=5):
     return rows
 
 
-def pmc_traffic(prefix="conv_wgrad2_kernel<2, 2, 4, 2>"):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (collected in separate
-    rocprofv3 --pmc passes of this same command; FETCH_SIZE x2 on gfx950 + WRITE_SIZE); (None, reason) if absent."""
+def _profile_rows(kind, prefix):
+    """(file, [(launches, value)]) of every kernel instantiation whose name starts with `prefix` in the newest committed summary
+    profiles/rNN_<kind>.txt; the value is the last (pmc_traffic: corrected MB per launch) or the MFMA-utilisation column."""
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r03_pmc_traffic.txt", "r02_pmc_traffic.txt", "r01_pmc_traffic.txt"):          # newest committed summary first
+    for rnd in ("r04", "r03", "r02", "r01"):                        # newest committed summary first
+        name = f"{rnd}_{kind}.txt"
+        rows = []
         try:
             for line in open(os.path.join(root, name)):
                 if line.startswith(prefix):
-                    return int(float(line.split("|")[-1]) * 1024 * 1024), f"profiles/{name} (separate --pmc passes)"
-        except OSError:
-            pass
-    return None, "no PMC summary found"
+                    c = [x.strip() for x in line.split("|")]
+                    rows.append((int(c[1]), float(c[-1] if kind == "pmc_traffic" else c[4])))
+        except (OSError, ValueError, IndexError):
+            continue
+        if rows:
+            return f"profiles/{name}", rows
+    return None, []
+
+
+def pmc_traffic(prefix):
+    """HBM bytes per launch of a kernel FAMILY (every instantiation whose name starts with `prefix`, weighted by the launches
+    sampled - the same launch set as the HIP-event figures) from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this command; FETCH_SIZE x2 on gfx950); (None, reason) if absent."""
+    src, rows = _profile_rows("pmc_traffic", prefix)
+    if not rows:
+        return None, "no PMC summary found"
+    n = sum(r[0] for r in rows)
+    return int(sum(r[0] * r[1] for r in rows) / n * 1024 * 1024), f"{src} ({len(rows)} instantiation(s), {n} launches sampled; separate --pmc passes)"
+
+
+def pmc_mfma_busy(prefix):
+    """SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x elapsed cycles) of the same family, launches-weighted (own --pmc pass: solo)."""
+    src, rows = _profile_rows("mfma_util", prefix)
+    if not rows:
+        return None, "no MFMA-busy summary found"
+    n = sum(r[0] for r in rows)
+    return round(sum(r[0] * r[1] for r in rows) / n, 4), f"{src} ({n} launches sampled, counter pass serialises the kernels)"
 
 
 def main():
@@ -285,14 +310,14 @@ def main():
         # kernel families as the library names them (mgd_last_kernel): description + the kernel-name prefix of the PMC summary
         fam = {
             "conv_gather_gemm(global weight fragments)": ("conv_gemm8_kernel<2,3> (128x128-tile bf16 MFMA gather-GEMM, weight fragments from "
-                                                          "global memory, pixel tile through an LDS-DMA ring, three blocks per CU)", "conv_gemm8_kernel<2, 3,"),
-            "conv_gather_gemm(producer/consumer)": ("conv_gemm6_kernel<2,2,4,4,4> (128x128-tile gather-GEMM, producer/consumer waves)", "conv_gemm6_kernel<2, 2, 4, 4"),
+                                                          "global memory, pixel tile through an LDS-DMA ring, three blocks per CU)", "conv_gemm8_kernel<"),
+            "conv_gather_gemm(producer/consumer)": ("conv_gemm6_kernel<2,2,4,4,4> (128x128-tile gather-GEMM, producer/consumer waves)", "conv_gemm6_kernel<"),
             "conv_gather_gemm(counted pipeline)": ("conv_gemm9_kernel<4,NT,NST> (gather-GEMM, hand-counted asm memory pipeline, two blocks per CU)", "conv_gemm9_kernel<4,"),
             "conv_gather_gemm(counted pipeline, ping-pong)": ("conv_gemm9_kernel<8,8,4,true> (256x128-tile gather-GEMM, 8 waves in ping-pong phases)", "conv_gemm9_kernel<8,"),
-            "conv_gather_gemm(streaming ping-pong)": ("conv_gemm10_kernel (256-channel streaming ping-pong gather-GEMM)", "conv_gemm10_kernel"),
-            "conv_wgrad(descriptor-addressed)": ("conv_wgrad4_kernel<2,2,4,2> (128x64-tile bf16 MFMA weight gradient, per-tap blocks, split-K, "
-                                                 "descriptor-addressed operands, three blocks per CU)", "conv_wgrad4_kernel<2, 2, 4, 2, 2,"),
-            "conv_wgrad": ("conv_wgrad2_kernel (per-tap weight gradient, carried addresses: stride-2 layers)", "conv_wgrad2_kernel<2, 2, 4, 2>"),
+            "conv_gather_gemm(phased, 8 waves)": ("conv_gemm12_kernel (256x192-tile gather-GEMM, 8 waves, both operands by LDS-DMA, counted vmcnt across barriers)", "conv_gemm12_kernel<"),
+            "conv_wgrad(descriptor-addressed)": ("conv_wgrad4_kernel (128x64-tile bf16 MFMA weight gradient, per-tap blocks, split-K, "
+                                                 "descriptor-addressed operands; all its instantiations: 3x3 and 1x1 launches)", "conv_wgrad4_kernel<"),
+            "conv_wgrad": ("conv_wgrad2_kernel (per-tap weight gradient, carried addresses: stride-2 layers)", "conv_wgrad2_kernel<"),
         }
         step_ms = dt * 1e3 / args.steps
 
@@ -302,17 +327,24 @@ def main():
             ms = sum(p[0].elapsed_time(p[1]) for p in sel)
             n = len(sel)
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            by = sum(p[5] for p in sel)
             return {"achieved": round(ach, 2), "frac": round(ach / PEAK_BF16_TFLOPS, 4), "launches": n,
                     "avg_launch_us": round(1e3 * ms / max(n, 1), 2), "share_of_step_time": round(ms / step_ms, 3),
-                    "algorithmic_flop_per_launch_avg": round(fl / max(n, 1) / 1e9, 2)}
+                    "algorithmic_flop_per_launch_avg": round(fl / max(n, 1) / 1e9, 2),
+                    "algorithmic_bytes_per_launch_avg": int(by / max(n, 1))}
         tags = sorted({p[3] for p in prof})
         per = {t: summarise(t) for t in tags}
         big = [t for t in tags if t in fam]                              # the large-tile MFMA kernels
         dom = max(big, key=lambda t: per[t]["share_of_step_time"])       # the kernel the step spends most time in
-        traffic, tsrc = pmc_traffic(fam[dom][1])
+        traffic, tsrc = pmc_traffic(fam[dom][1])                         # the whole family: the launch set of frac / avg_launch_us
+        busy, bsrc = pmc_mfma_busy(fam[dom][1])
+        alg = per[dom]["algorithmic_bytes_per_launch_avg"]
         roof = {"bound": "mfma", "kernel": fam[dom][0], "achieved": per[dom]["achieved"], "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": per[dom]["frac"], "traffic": traffic, "traffic_unit": "bytes/launch",
-                "traffic_source": tsrc, "launches": per[dom]["launches"], "avg_launch_us": per[dom]["avg_launch_us"],
+                "traffic_source": tsrc, "algorithmic_bytes_per_launch": alg,
+                "traffic_over_algorithmic": round(traffic / alg, 2) if traffic and alg else None,
+                "mfma_busy": busy, "mfma_busy_source": bsrc,
+                "launches": per[dom]["launches"], "avg_launch_us": per[dom]["avg_launch_us"],
                 "event_steps": 1, "share_of_step_time": per[dom]["share_of_step_time"],
                 "algorithmic_flop_per_launch_avg": per[dom]["algorithmic_flop_per_launch_avg"],
                 "note": "HIP events on the launch stream around every conv launch of the last timed step; the backward pass "

@@ -74,18 +74,26 @@ class _ProcessLoader:
     batch assembly, ... hold the GIL) stretched the step from 13.4 to 18.3 ms with the loader itself needing 11.9 ms per
     batch - the two sides were serialised by the interpreter lock, not by the machine."""
 
-    def __init__(self, num_workers, slots, slot_bytes):
+    def __init__(self, num_workers, slots, slot_bytes, start_timeout=120.0):
         import queue
         import secrets
         import subprocess
         import sys
         import tempfile
         import threading
+        import time
         from multiprocessing import shared_memory
         from multiprocessing.connection import Listener
         self.slot_bytes = int(slot_bytes)
         self.shm = shared_memory.SharedMemory(create=True, size=int(slots) * self.slot_bytes)
         self.tasks = queue.Queue()
+        # Epoch bookkeeping (ADVICE round 3): every task carries the token of the epoch that queued it.  abandon() - the
+        # teardown of an iterator that was left early (break, exception, steps_per_epoch < len) - bumps the token, so queued
+        # tasks of the old epoch are dropped, and waits for the tasks the workers are executing right now: only then may the
+        # next epoch hand out the slots they write into.
+        self.lock = threading.Lock()
+        self.idle = threading.Condition(self.lock)
+        self.epoch, self.inflight, self.alive = 0, 0, num_workers
         self.dir = tempfile.mkdtemp(prefix="mgd_loader_")
         address = os.path.join(self.dir, "sock")
         key = secrets.token_bytes(16)
@@ -93,25 +101,106 @@ class _ProcessLoader:
         env = dict(os.environ)
         root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-        self.procs = [subprocess.Popen([sys.executable, "-m", "multigriddet_amd.host_io", address, key.hex(), self.shm.name],
+        env["MGD_LOADER_KEY"] = key.hex()             # through the environment: argv is world-readable in /proc
+        self.procs = [subprocess.Popen([sys.executable, "-m", "multigriddet_amd.host_io", address, "-", self.shm.name],
                                        env=env, close_fds=True) for _ in range(num_workers)]
-        self.conns = [self.listener.accept() for _ in range(num_workers)]
+        # accept with a deadline and a liveness check: a worker that cannot start (import error, ...) must not hang the trainer
+        self.conns = []
+        acc_err = []
+
+        def accept_all():
+            try:
+                for _ in range(num_workers):
+                    self.conns.append(self.listener.accept())
+            except Exception as e:                     # listener closed by the timeout path below, or a bad handshake
+                acc_err.append(e)
+        at = threading.Thread(target=accept_all, daemon=True, name="mgd-loader-accept")
+        at.start()
+        deadline = time.monotonic() + start_timeout
+        while at.is_alive():
+            at.join(timeout=0.2)
+            dead = [p.returncode for p in self.procs if p.poll() is not None]
+            if dead or acc_err or time.monotonic() > deadline:
+                why = f"worker exited with code {dead[0]}" if dead else (str(acc_err[0]) if acc_err else f"no connection within {start_timeout:.0f} s")
+                self.threads = []
+                try:
+                    self.listener.close()
+                except Exception:
+                    pass
+                for p in self.procs:
+                    p.kill()
+                self.close()
+                raise RuntimeError(f"loader worker failed to start: {why}")
         self.threads = [threading.Thread(target=self._feed, args=(c,), daemon=True, name=f"mgd-loader-{i}")
                         for i, c in enumerate(self.conns)]
         for t in self.threads:
             t.start()
 
+    def begin_epoch(self):
+        with self.lock:
+            return self.epoch
+
+    def submit(self, token, task, done):
+        self.tasks.put((token, task, done))
+
+    def abandon(self, timeout=30.0):
+        """End of an iterator (complete or not): nothing of its epoch may run or be running when this returns."""
+        import queue
+        import time
+        with self.lock:
+            self.epoch += 1
+        try:
+            while True:                                # queued, never sent
+                item = self.tasks.get_nowait()
+                if item is None:
+                    self.tasks.put(None)
+                    break
+                item[2]((b"", 0, "abandoned epoch"))
+        except queue.Empty:
+            pass
+        deadline = time.monotonic() + timeout
+        with self.lock:
+            while self.inflight > 0 and time.monotonic() < deadline:
+                self.idle.wait(timeout=0.2)
+            if self.inflight > 0:
+                raise RuntimeError("loader workers did not finish the abandoned epoch's tasks")
+
     def _feed(self, conn):
+        import queue
         while True:
             item = self.tasks.get()
             if item is None:
                 return
-            task, done = item
+            token, task, done = item
+            with self.lock:
+                stale = token != self.epoch
+                if not stale:
+                    self.inflight += 1
+            if stale:
+                done((b"", 0, "abandoned epoch"))
+                continue
+            dead = None
             try:
                 conn.send(task)
-                done(conn.recv())
+                res = conn.recv()
             except (EOFError, OSError) as e:
-                done((b"", 0, f"loader worker died: {e}"))
+                dead, res = e, (b"", 0, f"loader worker died: {e}")
+            with self.lock:
+                self.inflight -= 1
+                if dead is not None:
+                    self.alive -= 1
+                last = self.alive == 0
+                self.idle.notify_all()
+            done(res)
+            if dead is not None:
+                if last:                               # nobody is left to run what is queued: fail it instead of hanging
+                    try:
+                        while True:
+                            it = self.tasks.get_nowait()
+                            if it is not None:
+                                it[2]((b"", 0, "all loader workers died"))
+                    except queue.Empty:
+                        pass
                 return
 
     def close(self):
@@ -314,6 +403,7 @@ class MultiGridDataGenerator:
         n = len(self)
         q = queue.Queue(maxsize=self.prefetch_factor)
         stop = threading.Event()
+        self._thread_devices = []                       # test hook: the device index each helper thread bound to
         cap = self.max_boxes_per_image * (self._calculate_expansion_factor() if self.augment else 1)
         use_proc = self.worker_mode == "process" and self.num_workers > 1
         dtype = np.float32 if self.host_augment else np.uint8
@@ -323,9 +413,14 @@ class MultiGridDataGenerator:
             slot = self.batch_size * hmax * wmax * 3 * np.dtype(dtype).itemsize
             self._ploader = _ProcessLoader(self.num_workers, self.prefetch_factor + 2, slot)
         free_slots = queue.Queue()
+        token = 0
         if use_proc:
+            token = self._ploader.begin_epoch()
             for k in range(self.prefetch_factor + 2):
                 free_slots.put(k)
+        # the helper threads inherit no CUDA device: every rank > 0 would otherwise pin memory and enqueue copies against
+        # device 0 (torch's own DataLoader pin thread sets the device for the same reason)
+        dev_index = torch.cuda.current_device() if torch.cuda.is_available() else None
 
         def make_done(boxes, state, fin):
             """Completion callback of ONE batch (its own boxes / counters: closures bind names, not values)."""
@@ -365,8 +460,8 @@ class MultiGridDataGenerator:
                 fin = threading.Event()
                 done = make_done(boxes, state, fin)
                 for j, (line, target, out, seed) in enumerate(jobs):
-                    pl.tasks.put(((slot * pl.slot_bytes + j * per, line, target, out, seed, self.host_augment),
-                                  (lambda res, j=j, d=done: d(res, j))))
+                    pl.submit(token, (slot * pl.slot_bytes + j * per, line, target, out, seed, self.host_augment),
+                              (lambda res, j=j, d=done: d(res, j)))
                 # the next batch's tasks may go out as soon as a slot is free: completion is awaited in order by a helper
                 item = (slot, (self.batch_size, H, W, 3), boxes, state, fin)
                 while not stop.is_set():
@@ -378,6 +473,9 @@ class MultiGridDataGenerator:
 
         def produce():
             try:
+                if dev_index is not None:
+                    torch.cuda.set_device(dev_index)
+                self._thread_devices.append(dev_index)
                 if use_proc:
                     produce_proc()
                     return
@@ -406,7 +504,9 @@ class MultiGridDataGenerator:
                 raise item
             if use_proc:
                 slot, shape, boxes, state, fin = item
-                fin.wait()
+                while not fin.wait(0.2):                # (a dead loader must not park this thread for ever)
+                    if stop.is_set():
+                        raise RuntimeError("prefetch iterator closed")
                 if state["err"] is not None:
                     raise RuntimeError(state["err"])
                 view = np.ndarray(shape, dtype, buffer=self._ploader.shm.buf, offset=slot * self._ploader.slot_bytes)
@@ -429,6 +529,9 @@ class MultiGridDataGenerator:
 
         def uploader():
             try:
+                if dev_index is not None:
+                    torch.cuda.set_device(dev_index)
+                self._thread_devices.append(dev_index)
                 for _ in range(n):
                     if stop.is_set():
                         return
@@ -466,3 +569,5 @@ class MultiGridDataGenerator:
                     pass
             th.join(timeout=5.0)
             ut.join(timeout=5.0)
+            if use_proc and self._ploader is not None:
+                self._ploader.abandon()                 # no task of this epoch is queued or running any more

@@ -110,6 +110,8 @@ def worker_main(address, authkey_hex, shm_name):
         os.nice(5)      # the trainer's own threads (600 kernel launches per step) come first when the cores are oversubscribed
     except OSError:
         pass
+    if authkey_hex == "-":                             # the key travels in the environment, not on the command line
+        authkey_hex = os.environ.pop("MGD_LOADER_KEY")
     conn = Client(address, family="AF_UNIX", authkey=bytes.fromhex(authkey_hex))
     shm = shared_memory.SharedMemory(name=shm_name)
     try:

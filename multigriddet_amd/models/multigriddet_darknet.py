@@ -112,9 +112,17 @@ class MultiGridDetModel:
                 st["eager"] += 1
                 return self.net.forward(xt)
             st["x"] = xt.clone()
+            # the capture runs on a stream of this model's own; its latency workspace (uncached memory: an allocation and a
+            # device synchronisation) must exist before the capture starts.  Replays use that workspace: replay one model's
+            # graphs from one stream at a time.
+            cs = getattr(self, "_capture_stream", None)
+            if cs is None:
+                cs = self._capture_stream = torch.cuda.Stream(self.net.device)
+            with torch.cuda.stream(cs):
+                self.net.latency_workspace()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=cs):
                 st["outs"] = self.net.forward(st["x"])
             st["graph"] = g
         if xt.data_ptr() != st["x"].data_ptr():

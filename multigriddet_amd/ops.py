@@ -48,7 +48,11 @@ def _launch_gemm(d, what):
     _gather_gemm(lib, d, what)
     e1.record()
     variant = lib.mgd_last_kernel().decode()      # the kernel family the library dispatched this launch to
-    PROFILE.append((e0, e1, 2.0 * d.N * d.Hg * d.Wg * d.ntaps * d.Ci * d.Co, variant, what))
+    # algorithmic bytes: source + packed weights + destination (+ residual addend, + the y of a fused BN-backward reduction)
+    nd = d.N * d.Hd * d.Wd * d.Co
+    by = 2.0 * d.N * d.Hs * d.Ws * d.Ci + 2.0 * d.Co_pad * d.K_pad + nd * (4 if d.dst_f32 else 2) + \
+        (2.0 * nd if d.addend else 0.0) + (2.0 * nd if d.bn_y else 0.0)
+    PROFILE.append((e0, e1, 2.0 * d.N * d.Hg * d.Wg * d.ntaps * d.Ci * d.Co, variant, what, by))
 
 
 def _ru(x, m):
@@ -375,7 +379,8 @@ def conv_wgrad(x, dy, dw, k, s, splits=None):
     L.check(L.load().mgd_conv_wgrad(C.byref(d), L.stream_ptr()), "conv_wgrad")
     e1.record()
     variant = L.load().mgd_last_kernel().decode()
-    PROFILE.append((e0, e1, 2.0 * N * Ho * Wo * k * k * Ci * Co, variant, "conv_wgrad"))
+    PROFILE.append((e0, e1, 2.0 * N * Ho * Wo * k * k * Ci * Co, variant, "conv_wgrad",
+                    2.0 * x.numel() + 2.0 * dy.numel() + 4.0 * Co * k * k * Ci))          # x + dy read once, fp32 dW written once
     return dw
 
 

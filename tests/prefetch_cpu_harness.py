@@ -20,6 +20,11 @@ torch.cuda.Event = FakeEvent
 class CS:
     def wait_event(self, e): pass
 torch.cuda.current_stream = lambda: CS()
+_dev = {"main": 3}
+import threading
+torch.cuda.current_device = lambda: _dev.get(threading.get_ident(), _dev["main"])
+def _set_device(i): _dev[threading.get_ident()] = i
+torch.cuda.set_device = _set_device
 torch.Tensor.cuda = lambda self, non_blocking=False: self
 torch.Tensor.record_stream = lambda self, s: None
 G.MultiGridDataGenerator._host_buffer = staticmethod(lambda shape, dtype, pinned: np.zeros(shape, dtype))
@@ -44,3 +49,26 @@ for aug in (False, True):
     for (ia,ba),(ib,bb) in zip(a,b):
         assert torch.equal(ia.float(), ib.float()) and torch.equal(ba, bb)
     print('aug', aug, 'ok', len(a))
+
+# abandoned epoch: leave an epoch after ONE batch; the next epoch's batches must still equal thread mode -
+# a stale task of the abandoned epoch must neither run later nor overwrite a slot the new epoch has filled
+def run_abandon(mode):
+    g=G.MultiGridDataGenerator(lines, 2, (64,64), anchors, 80, augment=False, shuffle=True, seed=1, num_workers=3, prefetch_factor=3, worker_mode=mode)
+    out=[]
+    for rep in range(3):
+        it = iter(g)
+        x, _z = next(it)
+        out.append((x[0].clone(), x[1].clone()))
+        it.close()                                   # the generator's finally: runs the teardown
+        g.on_epoch_end()
+    for (x, _z) in g:
+        out.append((x[0].clone(), x[1].clone()))
+    devs = list(g._thread_devices)
+    g.close()
+    return out, devs
+(a, da), (b, db) = run_abandon('process'), run_abandon('thread')
+assert len(a) == len(b) == 3 + 5, (len(a), len(b))
+for (ia,ba),(ib,bb) in zip(a,b):
+    assert torch.equal(ia.float(), ib.float()) and torch.equal(ba, bb)
+assert da == [3, 3] and db == [3, 3], (da, db)    # both helper threads bound to the creator's device, not to device 0
+print('abandon ok', len(a))

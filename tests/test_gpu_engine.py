@@ -474,3 +474,53 @@ def test_early_optimizer_matches_tail_optimizer():
     assert d.max().item() <= 2.5 * lr
     assert d.mean().item() <= 0.02 * lr
     assert (ma - mb).abs().max().item() <= 1e-3 * ma.abs().max().item() + 1e-7
+
+
+def test_two_models_on_two_streams_share_no_latency_state():
+    """"no global mutable state; safe to call concurrently on different streams".  The batch-1 forward runs the
+    latency-form convolutions (K ranges met inside the kernel through tickets + partial tiles in uncached memory); that
+    workspace belongs to the CALLER - one ops.LatencyWorkspace per (Network, stream), the library keeps none.  Two folded
+    models at 608 x 608, batch 1, driven from two streams with their launches interleaved and no synchronisation in between,
+    must each return exactly what they return alone, run after run, and leave every ticket at zero."""
+    import torch
+    from multigriddet_amd import ops
+    from multigriddet_amd.models import build_multigriddet_darknet
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    models, xs = [], []
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        m, _ = build_multigriddet_darknet(input_shape=(608, 608, 3), num_classes=80)
+        for cv in m.net.layers:                      # distinct, non-trivial moving statistics per model
+            if cv.bn:
+                cv.mm.copy_((torch.randn(cv.cout, generator=g) * 0.05).to(dev))
+                cv.mv.copy_((torch.rand(cv.cout, generator=g) + 3.0).to(dev))
+                cv.w.copy_((torch.randn(cv.w.shape, generator=g) * (1.5 / (cv.T * cv.cin) ** 0.5)).to(dev))
+        m.net.refresh_packed()
+        m.fold_bn(True)
+        models.append(m)
+        xs.append(torch.rand(1, 608, 608, 3, generator=g).to(dev))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    serial = []
+    for m, x, s in zip(models, xs, streams):         # each alone on its stream
+        with torch.cuda.stream(s):
+            serial.append([o.clone() for o in m(x)])
+        torch.cuda.synchronize()
+    assert not all(torch.equal(a, b) for a, b in zip(*serial))            # two different networks
+    fam = set()
+    for rnd in range(4):                             # together: launches interleaved, nothing waits for anything
+        outs = [None, None]
+        for i in (0, 1) if rnd % 2 == 0 else (1, 0):
+            with torch.cuda.stream(streams[i]):
+                outs[i] = [o.clone() for o in models[i](xs[i])]
+                fam.add(ops.L.load().mgd_last_kernel())
+        torch.cuda.synchronize()
+        for i in (0, 1):
+            for o, e in zip(outs[i], serial[i]):
+                assert torch.equal(o, e), (rnd, i)
+    wss = [ws for m in models for ws in m.net._lat_ws.values()]
+    assert len(wss) == 2 and wss[0].ptr != wss[1].ptr                     # one workspace per (network, stream)
+    for i, s in enumerate(streams):
+        with torch.cuda.stream(s):
+            for ws in models[i].net._lat_ws.values():
+                assert not ws.tickets().any()
