@@ -167,7 +167,7 @@ def test_process_loader_matches_in_process_decode(tmp_path):
                 res[j] = r
                 fin.release()
             for j, line in enumerate(lines):
-                pl.tasks.put(((j * per, line, (S, S), (S, S), 100 + j, aug), (lambda r, j=j: done(r, j))))
+                pl.submit(pl.begin_epoch(), (j * per, line, (S, S), (S, S), 100 + j, aug), (lambda r, j=j: done(r, j)))
             for _ in lines:
                 assert fin.acquire(timeout=120)
             for j, line in enumerate(lines):
