@@ -175,16 +175,23 @@ typedef struct mgd_wgrad_desc {
    * form_arg: MGD_WGRAD_DESC - ring depth 2 / 3 / 4 (0 = by layer). */
   int32_t form;
   int32_t form_arg;
+  /* Optional workspace of the kernel-row form (MGD_WGRAD_ROW): with at least mgd_conv_wgrad_workspace_size(d) bytes its blocks
+   * store per-split fp32 slabs with plain stores and a second launch adds them into dw (the fp32 atomics of 256 blocks x 192 KiB
+   * run at a fifth of the store rate); without it the form uses atomics.  Caller-owned, one per stream. */
+  float* partial;
+  int64_t partial_bytes;
 } mgd_wgrad_desc;
 
 enum {
   MGD_WGRAD_AUTO = 0,
   MGD_WGRAD_PERTAP = 2,   /* conv_wgrad2_kernel: per-tap blocks, carried source coordinates (any stride)            */
   MGD_WGRAD_PATCH = 3,    /* conv_wgrad3_kernel: all nine taps of a [64 co] x [Ci] slice per block (Ci = 32 / 64)   */
-  MGD_WGRAD_DESC = 4      /* conv_wgrad4_kernel: per-tap blocks, raw buffer descriptors (stride-1 'same' layers)    */
+  MGD_WGRAD_DESC = 4,     /* conv_wgrad4_kernel: per-tap blocks, raw buffer descriptors (stride-1 'same' layers)    */
+  MGD_WGRAD_ROW = 5       /* conv_wgrad5_kernel: 128 x 128 x (three taps of a kernel row) blocks, 8 waves           */
 };
 
 int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream);
+int64_t mgd_conv_wgrad_workspace_size(const mgd_wgrad_desc* d);
 
 /* Stem conv 3x3, Cin=3 -> Cout=32, stride 1, 'same' (models/backbones/darknet.py:21).  image f32 [N,H,W,3];
  * w f32 [32][3][3][3] (OHWI); y bf16 [N,H,W,32].  mgd_stem_fwd runs on the matrix cores straight from the fp32 image

@@ -54,6 +54,7 @@ class WgradDesc(C.Structure):
         ("Hg", C.c_int32), ("Wg", C.c_int32), ("Co", C.c_int32),
         ("in_stride", C.c_int32), ("ntaps", C.c_int32), ("dh", C.c_int32 * 9), ("dw_off", C.c_int32 * 9),
         ("splits", C.c_int32), ("form", C.c_int32), ("form_arg", C.c_int32),
+        ("partial", C.c_void_p), ("partial_bytes", C.c_int64),
     ]
 
 
@@ -105,7 +106,7 @@ class DecodeCfg(C.Structure):
 
 # every symbol include/mgd_hip.h declares
 EXPORTS = [
-    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_latency_workspace_size", "mgd_uncached_alloc", "mgd_uncached_free", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_stem_fwd", "mgd_stem_fwd_act", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
+    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_latency_workspace_size", "mgd_uncached_alloc", "mgd_uncached_free", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_conv_wgrad_workspace_size", "mgd_stem_fwd", "mgd_stem_fwd_act", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
     "mgd_pack_weights", "mgd_pack_weights_batch", "mgd_stem_im2col", "mgd_bn_finalize", "mgd_bn_act_fwd", "mgd_bn_act_fwd_fused", "mgd_bn_act_bwd_reduce", "mgd_bn_act_bwd_apply",
     "mgd_upsample_concat_fwd", "mgd_upsample_concat_bwd", "mgd_bias_grad", "mgd_f32_to_bf16", "mgd_bf16_to_f32",
     "mgd_adam_step", "mgd_adam_step_dev", "mgd_sgd_step", "mgd_build_targets_workspace_size", "mgd_build_targets",
@@ -151,6 +152,7 @@ def load():
                  "mgd_nms_workspace_size", "mgd_wbf_workspace_size", "mgd_letterbox_workspace_size"):
         getattr(lib, name).restype = C.c_size_t
     lib.mgd_latency_workspace_size.restype = C.c_int64
+    lib.mgd_conv_wgrad_workspace_size.restype = C.c_int64
     lib.mgd_uncached_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
     lib.mgd_uncached_free.argtypes = [C.c_void_p]
     lib.mgd_latency_tickets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -55,6 +55,26 @@ struct GemmArgs {
   unsigned* tickets;           //   and one arrival counter per tile (zero between launches)
 };
 
+struct WgradArgs {
+  const bf16_t* src;
+  const bf16_t* dy;
+  float* dw;
+  int N, Hs, Ws, Ci, Hg, Wg, Co;
+  int in_stride, ntaps;
+  unsigned long long tapcode;
+  int P;          // N*Hg*Wg
+  int chunk;      // pixels per split (multiple of 64)
+  int splits, tilesCo, tilesCi;
+  float rcp_hw, rcp_w;
+  int dbg;        // diagnostics (MGD_DBG): 16 = plain stores instead of atomics, 32 = no epilogue at all
+  float* slab;            // conv_wgrad5_kernel: caller's workspace for the splits' fp32 slabs (null: fp32 atomics)
+  long long slab_bytes;
+};
+
+// conv_wgrad5.hip: kernel-row weight gradient (128 x 128 x 3 taps per block, 8 waves); MGD_EINVAL when the geometry does not apply
+int launch_wgrad5(WgradArgs& a, hipStream_t st);
+long long wgrad5_workspace_bytes(WgradArgs a);
+
 // conv_gemm12.hip: the phased 8-wave gather-GEMM (shape: see the launcher); returns 0 or MGD_EINVAL when the shape does not apply
 int launch_gemm12(GemmArgs& a, int shape, int kranges, hipStream_t st);
 

@@ -1,21 +1,12 @@
 // Weight gradient of the convolution engine (gfx950): per-tap blocks on v_mfma_f32_16x16x32_bf16 with transposed LDS reads.
 #include "conv_common.hpp"
 
+extern "C" int64_t mgd_conv_wgrad_workspace_size(const mgd_wgrad_desc* d);
+
 namespace {
 
-struct WgradArgs {
-  const bf16_t* src;
-  const bf16_t* dy;
-  float* dw;
-  int N, Hs, Ws, Ci, Hg, Wg, Co;
-  int in_stride, ntaps;
-  unsigned long long tapcode;
-  int P;          // N*Hg*Wg
-  int chunk;      // pixels per split (multiple of 64)
-  int splits, tilesCo, tilesCi;
-  float rcp_hw, rcp_w;
-  int dbg;        // diagnostics (MGD_DBG): 16 = plain stores instead of atomics, 32 = no epilogue at all
-};
+using mgd::WgradArgs;
+
 
 // (one raw barrier per 64-pixel K-step, the next stage's loads in flight during the MFMAs).
 template <int WC, int WI, int MT, int NT>
@@ -957,12 +948,37 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
   a.rcp_hw = 1.0f / (float)(d->Hg * d->Wg);
   a.rcp_w = 1.0f / (float)d->Wg;
   a.dbg = MGD_DIAG_FLAGS;
+  a.slab = d->partial; a.slab_bytes = d->partial_bytes;
   hipStream_t st = (hipStream_t)stream;
   const int co = d->Co, ci = d->Ci, form = d->form;
-  MGD_REQUIRE(form == MGD_WGRAD_AUTO || form == MGD_WGRAD_PERTAP || form == MGD_WGRAD_PATCH || form == MGD_WGRAD_DESC, "wgrad: unknown kernel form %d", form);
+  MGD_REQUIRE(form == MGD_WGRAD_AUTO || form == MGD_WGRAD_PERTAP || form == MGD_WGRAD_PATCH || form == MGD_WGRAD_DESC || form == MGD_WGRAD_ROW,
+              "wgrad: unknown kernel form %d", form);
   // patch form: 3x3 in the standard tap order, Ci = 32 or 64, output map at least 16 wide
   bool std9 = d->ntaps == 9;
   for (int t = 0; t < 9 && std9; ++t) std9 = d->dh[t] == t / 3 - 1 && d->dw_off[t] == t % 3 - 1;
+  // stride-1 'same' geometry (every 1x1, every stride-1 3x3): descriptor-addressed form, no per-pixel address arithmetic.
+  // 128 x 64 tiles: 48 KB of LDS, so three blocks share a CU - 8 % faster over the graph than 128 x 128 with two, although a
+  // block stages half as many MACs per LDS-DMA byte (three waves per SIMD hide the ring's round trips better).
+  const bool lin = d->in_stride == 1 && d->Hs == d->Hg && d->Ws == d->Wg &&
+                   (long long)a.chunk * (co > ci ? co : ci) * 2 < (1ll << 31) && d->Hg * d->Wg <= 64 * 1024;
+  // kernel-row form (conv_wgrad5.hip): one dy tile and one input tile for the three taps of a kernel row, 128 x 128 x 3 blocks
+  {
+    const bool can_row = lin && (std9 || d->ntaps == 1) && d->Wg >= 8;
+    MGD_REQUIRE(form != MGD_WGRAD_ROW || can_row, "wgrad: the kernel-row form needs a stride-1 'same' layer, 3x3 in the standard tap order or 1x1, at least 8 pixels wide");
+    // Own rule (tools/bench_wgrad_forms.py, 608 x 608, batch 16, each launch alone): with a slab workspace it beats the per-tap
+    // form on the 3x3 layers with Co >= 128, Ci >= 64 and enough pixels for one block per CU - 128 -> 256 at 76 x 76 82 -> 73 us,
+    // 256 -> 512 at 38 x 38 77 -> 72, 512 -> 1024 at 19 x 19 89 -> 77, 64 -> 128 at 152 x 152 124 -> 99 (patch form) - and loses
+    // with atomics, on the 1x1 layers and on the head's small maps.
+    // (the head's 3x3 layers leave a block only ~10 K-steps: there it loses 38 -> 42 us; hence the pixels-per-block floor)
+    const long long row_tiles = (long long)cdiv(co, 128) * cdiv(ci, 128) * 3;
+    const bool want_row = form == MGD_WGRAD_AUTO && can_row && std9 && co >= 128 && ci >= 64 && d->partial &&
+                          (long long)a.P * row_tiles >= 256ll * 1500 && d->partial_bytes >= mgd_conv_wgrad_workspace_size(d);
+    if (form == MGD_WGRAD_ROW || want_row) {
+      MGD_REQUIRE(mgd::launch_wgrad5(a, st) == MGD_OK, "wgrad: the kernel-row form refused the geometry");
+      MGD_CHECK_LAUNCH("conv_wgrad(kernel row)");
+      return MGD_OK;
+    }
+  }
   const bool can_patch = std9 && (ci == 32 || ci == 64) && co >= 32 && d->Wg >= 16 &&
       (d->in_stride == 1 || d->in_stride == 2) && d->Hs == d->Hg * d->in_stride && d->Ws == d->Wg * d->in_stride &&
       (long long)d->N * cdiv(d->Hg, 4) * cdiv(d->Wg, 16) * cdiv(co, 64) >= 256 * 16;   // >= 16 K-steps per block
@@ -983,11 +999,6 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
     MGD_CHECK_LAUNCH("conv_wgrad3");
     return MGD_OK;
   }
-  // stride-1 'same' geometry (every 1x1, every stride-1 3x3): descriptor-addressed form, no per-pixel address arithmetic.
-  // 128 x 64 tiles: 48 KB of LDS, so three blocks share a CU - 8 % faster over the graph than 128 x 128 with two, although a
-  // block stages half as many MACs per LDS-DMA byte (three waves per SIMD hide the ring's round trips better).
-  const bool lin = d->in_stride == 1 && d->Hs == d->Hg && d->Ws == d->Wg &&
-                   (long long)a.chunk * (co > ci ? co : ci) * 2 < (1ll << 31) && d->Hg * d->Wg <= 64 * 1024;
   const bool can_desc = lin && co > 32 && ci > 32;
   MGD_REQUIRE(form != MGD_WGRAD_DESC || can_desc, "wgrad: the descriptor-addressed form needs a stride-1 'same' layer with Ci, Co > 32");
   if ((form == MGD_WGRAD_AUTO || form == MGD_WGRAD_DESC) && can_desc) {
@@ -1012,4 +1023,15 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
   else launch_wgrad<2, 2, 1, 2>(a, st);
   MGD_CHECK_LAUNCH("conv_wgrad");
   return MGD_OK;
+}
+
+// Bytes of workspace (mgd_wgrad_desc.partial) with which the kernel-row form stores per-split slabs instead of issuing fp32
+// atomics; 0 when that form cannot run the geometry.
+extern "C" int64_t mgd_conv_wgrad_workspace_size(const mgd_wgrad_desc* d) {
+  if (!d || d->ntaps < 1 || d->ntaps > 9) return 0;
+  WgradArgs a{};
+  a.N = d->N; a.Hs = d->Hs; a.Ws = d->Ws; a.Ci = d->Ci; a.Hg = d->Hg; a.Wg = d->Wg; a.Co = d->Co;
+  a.in_stride = d->in_stride; a.ntaps = d->ntaps;
+  a.P = d->N * d->Hg * d->Wg;
+  return mgd::wgrad5_workspace_bytes(a);
 }

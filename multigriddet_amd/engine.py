@@ -69,6 +69,7 @@ class Network:
         self.fp32 = precision == "fp32"
         self.O = ops32 if self.fp32 else ops          # the op set forward / backward call
         self._lat_ws = {}                             # stream handle -> ops.LatencyWorkspace (latency_workspace())
+        self._wg_ws = None                            # fp32 slabs of the kernel-row weight gradient (_wgrad_workspace())
         self.act_dtype = torch.float32 if self.fp32 else torch.bfloat16
         self.device = torch.device(device)
         self.num_classes, self.num_anchors = num_classes, num_anchors
@@ -424,11 +425,22 @@ class Network:
                        reduced=i in A["reduced"])
         return dy
 
+    def _wgrad_workspace(self):
+        """fp32 workspace of the kernel-row weight gradient's per-split slabs (mgd_wgrad_desc.partial): one buffer per network,
+        used by the weight-gradient launches in stream order (they all run on one stream).  64 MB covers every layer of the
+        graph at batch 16, 608 x 608 (<= 256 slabs of a 128 x 128 x 3-tap tile); a launch that needs more falls back to atomics."""
+        if not ops.WGRAD_ROW_FORM:
+            return None
+        if self._wg_ws is None:
+            self._wg_ws = torch.empty(16 << 20, dtype=torch.float32, device=self.device)
+        return self._wg_ws
+
     def _wgrad(self, x, dy, dw, k, s, dbias=None):
         """Weight gradient (and, for the biased prediction convs, the bias gradient: nothing on the dgrad/BN chain
         reads it, so it leaves the critical stream too)."""
+        kw = {} if self.fp32 else {"ws": self._wgrad_workspace()}
         if not self.overlap_wgrad:
-            self.O.conv_wgrad(x, dy, dw, k, s)
+            self.O.conv_wgrad(x, dy, dw, k, s, **kw)
             if dbias is not None:
                 self.O.bias_grad(dy, dbias)
             return
@@ -436,7 +448,7 @@ class Network:
         ev.record()
         self.wg_stream.wait_event(ev)
         with torch.cuda.stream(self.wg_stream):
-            self.O.conv_wgrad(x, dy, dw, k, s)
+            self.O.conv_wgrad(x, dy, dw, k, s, **kw)
             if dbias is not None:
                 self.O.bias_grad(dy, dbias)
 

@@ -326,6 +326,7 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
 _S2_PATCH = os.environ.get("MGD_S2_PATCH", "1") != "0"
 _WGRAD_BLOCKS = int(os.environ.get("MGD_WGRAD_BLOCKS", "0"))      # 0: by tile shape
 # kernel form of the weight-gradient launches (mgd_wgrad_desc.form / form_arg; 0 = the library's dispatch): tests and tools
+WGRAD_ROW_FORM = os.environ.get("MGD_WGRAD_ROW", "1") == "1"      # engine: give the kernel-row form its slab workspace (0: never dispatched)
 WGRAD_FORM = int(os.environ.get("MGD_WGRAD_FORM", "0"))
 WGRAD_FORM_ARG = int(os.environ.get("MGD_WGRAD_FORM_ARG", "0"))
 
@@ -357,8 +358,9 @@ def wgrad_splits(P, co, ci, T, target_blocks=None):
     return best
 
 
-def conv_wgrad(x, dy, dw, k, s, splits=None):
-    """dw (fp32 [Co, k*k, Ci]) += x (*) dy."""
+def conv_wgrad(x, dy, dw, k, s, splits=None, ws=None):
+    """dw (fp32 [Co, k*k, Ci]) += x (*) dy.  ws: optional fp32 workspace tensor of the caller (one per stream) for the
+    kernel-row form's per-split slabs (mgd_wgrad_desc.partial)."""
     N, H, W, Ci = x.shape
     _, Ho, Wo, Co = dy.shape
     d = L.WgradDesc()
@@ -371,6 +373,8 @@ def conv_wgrad(x, dy, dw, k, s, splits=None):
         d.dh[i], d.dw_off[i] = a, b
     d.splits = splits if splits is not None else wgrad_splits(N * Ho * Wo, Co, Ci, k * k)
     d.form, d.form_arg = WGRAD_FORM, WGRAD_FORM_ARG
+    if ws is not None:
+        d.partial, d.partial_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     if PROFILE is None:
         L.check(L.load().mgd_conv_wgrad(C.byref(d), L.stream_ptr()), "conv_wgrad")
         return dw

@@ -163,7 +163,8 @@ def test_stem(dev):
 
 
 @pytest.mark.parametrize("form,arg,expect", [(2, 0, b"conv_wgrad"), (4, 0, b"conv_wgrad(descriptor-addressed)"),
-                                             (4, 3, b"conv_wgrad(descriptor-addressed)"), (4, 4, b"conv_wgrad(descriptor-addressed)")])
+                                             (4, 3, b"conv_wgrad(descriptor-addressed)"), (4, 4, b"conv_wgrad(descriptor-addressed)"),
+                                             (5, 0, b"conv_wgrad(kernel row)"), (5, 1, b"conv_wgrad(kernel row)")])
 def test_wgrad_forced_forms(dev, form, arg, expect, monkeypatch):
     """mgd_wgrad_desc.form / form_arg: every weight-gradient kernel form forced through the descriptor (the library reads no
     environment) against torch autograd on the same bf16 inputs - ragged pixel ranges, ragged Co, two Ci tiles; a form that
@@ -171,21 +172,34 @@ def test_wgrad_forced_forms(dev, form, arg, expect, monkeypatch):
     import torch.nn.functional as F
     from multigriddet_amd import ops
     monkeypatch.setattr(ops, "WGRAD_FORM", form)
-    monkeypatch.setattr(ops, "WGRAD_FORM_ARG", arg)
+    monkeypatch.setattr(ops, "WGRAD_FORM_ARG", 0 if form == 5 else arg)
+    # kernel-row form: arg 0 = fp32 atomics, 1 = per-split slabs in a caller-owned workspace + reduce launch
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=dev) if (form == 5 and arg == 1) else None
     torch.manual_seed(0)
-    for (N, H, W, Ci, Co) in ((2, 76, 76, 128, 256), (2, 21, 37, 256, 128), (1, 19, 19, 256, 704), (3, 38, 38, 128, 352)):
+    shapes = ((2, 76, 76, 128, 256), (2, 21, 37, 256, 128), (1, 19, 19, 256, 704), (3, 38, 38, 128, 352))
+    if form == 5:       # + a map narrower than a K-step, pixel ranges that start inside an image row, Ci = 64, several images
+        shapes += ((5, 9, 8, 128, 128), (2, 40, 33, 64, 128), (16, 19, 19, 128, 128))
+    for (N, H, W, Ci, Co) in shapes:
         x = torch.randn(N, H, W, Ci).to(torch.bfloat16)
         dy = torch.randn(N, H, W, Co).to(torch.bfloat16)
         w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
         F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=1).backward(dy.float().permute(0, 3, 1, 2))
         ref = w.grad.permute(0, 2, 3, 1).reshape(Co, 9, Ci)
         dw = torch.full((Co, 9, Ci), 0.5, device=dev)
-        ops.conv_wgrad(x.to(dev), dy.to(dev), dw, 3, 1)
+        ops.conv_wgrad(x.to(dev), dy.to(dev), dw, 3, 1, ws=ws)
         assert ops.L.load().mgd_last_kernel() == expect
         torch.cuda.synchronize()
         err = (dw.cpu() - 0.5 - ref).abs().max().item()
         assert err <= 2e-3 * ref.abs().max().item() + 1e-3, (N, H, W, Ci, Co, err)
-    if form == 4:                                      # stride 2 is not a 'same' layer: the descriptor form refuses it
+    if form == 5:                                      # 1x1 layers run on the same kernel (one tap, no pads)
+        x = torch.randn(3, 20, 24, 256).to(torch.bfloat16)
+        dy = torch.randn(3, 20, 24, 192).to(torch.bfloat16)
+        ref = torch.einsum("nhwo,nhwi->oi", dy.float(), x.float())
+        dw = torch.zeros(192, 1, 256, device=dev)
+        ops.conv_wgrad(x.to(dev), dy.to(dev), dw, 1, 1, ws=ws)
+        torch.cuda.synchronize()
+        assert (dw.cpu()[:, 0] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-3
+    if form in (4, 5):                                 # stride 2 is not a 'same' layer: these forms refuse it
         x = torch.randn(1, 16, 16, 64).to(torch.bfloat16).to(dev)
         dy = torch.randn(1, 8, 8, 128).to(torch.bfloat16).to(dev)
         with pytest.raises(ops.L.MgdError):

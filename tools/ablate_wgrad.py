@@ -9,6 +9,7 @@ from multigriddet_amd import ops
 flags, ci, co, h = (int(v) for v in sys.argv[1:5])
 k = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 lib.mgd_diag_set_flags(flags)
+ops.WGRAD_FORM = int(os.environ.get("WG_FORM", "0"))
 dev = torch.device("cuda:0")
 x = torch.randn(16, h, h, ci, device=dev).to(torch.bfloat16)
 dy = torch.randn(16, h, h, co, device=dev).to(torch.bfloat16)
