@@ -476,6 +476,29 @@ int mgd_upsample_concat_bwd_f32(const float* dout, float* du, float* dskip, int 
                                 void* stream);
 int mgd_bias_grad_f32(const float* dy, float* dbias, int64_t P, int C, void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Launch plans (csrc/plan.cpp).  A step's calls into this library are recorded once - entry point, arguments, stream slot,
+ * cross-stream waits - and replayed by ONE call that needs no interpreter: the counterpart of what `model.fit` does per
+ * batch in the reference (multigriddet/trainers/trainer.py:572-581), where Keras' executor, not Python, issues the kernels.
+ * Not a hipGraph: the streams stay separate hardware queues; only the host side of the launches moves to C.
+ *   mgd_plan_add_call: `name` = an int-returning entry point declared above; argument i is words[i] read by kinds[i]:
+ *     0 integer / pointer value, 1 float (bit pattern in the low 32 bits), 2 double (bit pattern), 3 pointer to
+ *     blob + words[i] (the blob - descriptors the call takes by pointer - is copied into the plan), 4 stream slot
+ *     (streams[words[i]] at replay), 5 parameter slot (params[words[i]] at replay: pointers that change from run to run).
+ *   mgd_plan_add_wait: at this point of the replay streams[waiting] waits for what streams[signalling] holds so far.
+ *   mgd_plan_run: replays in recording order; returns the first failing call's code (mgd_last_error has its message).
+ * A plan is immutable while it runs; one thread replays it at a time.  mgd_memset_async: hipMemsetAsync as an entry point,
+ * so that a step's buffer clears are part of its plan. */
+typedef struct mgd_plan mgd_plan;
+int mgd_plan_create(mgd_plan** out);
+int mgd_plan_destroy(mgd_plan* plan);
+int mgd_plan_size(const mgd_plan* plan);
+int mgd_plan_add_call(mgd_plan* plan, const char* name, const int64_t* words, const uint8_t* kinds, int nargs, const void* blob,
+                      int64_t blob_bytes);
+int mgd_plan_add_wait(mgd_plan* plan, int waiting, int signalling);
+int mgd_plan_run(const mgd_plan* plan, void* const* streams, int nstreams, void* const* params, int nparams);
+int mgd_memset_async(void* p, int value, int64_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,7 +106,7 @@ class DecodeCfg(C.Structure):
 
 # every symbol include/mgd_hip.h declares
 EXPORTS = [
-    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_latency_workspace_size", "mgd_uncached_alloc", "mgd_uncached_free", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_conv_wgrad_workspace_size", "mgd_stem_fwd", "mgd_stem_fwd_act", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
+    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_plan_create", "mgd_plan_destroy", "mgd_plan_size", "mgd_plan_add_call", "mgd_plan_add_wait", "mgd_plan_run", "mgd_memset_async", "mgd_latency_workspace_size", "mgd_uncached_alloc", "mgd_uncached_free", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_conv_wgrad_workspace_size", "mgd_stem_fwd", "mgd_stem_fwd_act", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
     "mgd_pack_weights", "mgd_pack_weights_batch", "mgd_stem_im2col", "mgd_bn_finalize", "mgd_bn_act_fwd", "mgd_bn_act_fwd_fused", "mgd_bn_act_bwd_reduce", "mgd_bn_act_bwd_apply",
     "mgd_upsample_concat_fwd", "mgd_upsample_concat_bwd", "mgd_bias_grad", "mgd_f32_to_bf16", "mgd_bf16_to_f32",
     "mgd_adam_step", "mgd_adam_step_dev", "mgd_sgd_step", "mgd_build_targets_workspace_size", "mgd_build_targets",
@@ -124,6 +124,136 @@ DIAG_EXPORTS = ["mgd_diag_set_flags", "mgd_diag_flags_value", "mgd_debug_stamps"
                 "mgd_debug_wgrad_skeleton", "mgd_debug_gemm_skeleton"]
 
 
+# ---------------------------------------------------------------------------------------------- launch plans (csrc/plan.cpp)
+RECORDER = None      # while set, load() returns a proxy that runs every entry point AND records it
+
+
+class Plan:
+    """A recorded sequence of C-ABI calls (mgd_plan_*), replayed by one call that holds no interpreter lock."""
+
+    def __init__(self, handle, streams, nparams):
+        self.handle, self.streams, self.nparams = handle, list(streams), nparams
+        self._sarr = (C.c_void_p * max(1, len(streams)))(*[s.cuda_stream for s in streams])
+        self._parr = (C.c_void_p * max(1, nparams))()
+        self.size = int(load().mgd_plan_size(handle))
+
+    def run(self, params=()):
+        assert len(params) == self.nparams
+        for i, t in enumerate(params):
+            self._parr[i] = t.data_ptr()
+        check(load().mgd_plan_run(self.handle, self._sarr, len(self.streams), self._parr, self.nparams), "plan_run")
+
+    def __del__(self):
+        try:
+            load().mgd_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Recorder:
+    """Records what goes through the library while it is active.  streams: the torch streams of the step in slot order (a call's
+    stream argument is matched against them); params: tensors whose addresses change from run to run (the batch) - a call
+    argument equal to one of these addresses is replayed from Plan.run(params)."""
+
+    def __init__(self, streams, params=()):
+        lib = load()
+        h = C.c_void_p()
+        check(lib.mgd_plan_create(C.byref(h)), "plan_create")
+        self.handle = h
+        self.streams = list(streams)
+        self.slots = {s.cuda_stream: i for i, s in enumerate(self.streams)}
+        self.params = {t.data_ptr(): i for i, t in enumerate(params)}
+        self.nparams = len(params)
+        self.error = None
+
+    def _slot(self, stream):
+        return self.slots[stream.cuda_stream]
+
+    def wait(self, waiting, signalling):
+        """`waiting` (torch stream) waits for what `signalling` holds at this point of the sequence."""
+        check(load().mgd_plan_add_wait(self.handle, self._slot(waiting), self._slot(signalling)), "plan_add_wait")
+
+    def add(self, name, args):
+        import struct
+        words, kinds, blob = [], [], bytearray()
+
+        def put_blob(raw):
+            while len(blob) % 16:
+                blob.append(0)
+            off = len(blob)
+            blob.extend(raw)
+            return off
+        for a in args:
+            if a is None:
+                words.append(0); kinds.append(0)
+            elif isinstance(a, bool) or isinstance(a, int):
+                v = int(a)
+                if v in self.params:
+                    words.append(self.params[v]); kinds.append(5)
+                else:
+                    words.append(v); kinds.append(0)
+            elif isinstance(a, float):
+                words.append(struct.unpack("<q", struct.pack("<d", a))[0]); kinds.append(2)
+            elif isinstance(a, C.c_float):
+                words.append(struct.unpack("<I", struct.pack("<f", a.value))[0]); kinds.append(1)
+            elif isinstance(a, C.c_double):
+                words.append(struct.unpack("<q", struct.pack("<d", a.value))[0]); kinds.append(2)
+            elif isinstance(a, C.c_void_p):
+                v = a.value or 0
+                if v in self.slots:
+                    words.append(self.slots[v]); kinds.append(4)
+                elif v in self.params:
+                    words.append(self.params[v]); kinds.append(5)
+                else:
+                    words.append(v); kinds.append(0)
+            elif isinstance(a, (C.Structure, C.Array)):
+                words.append(put_blob(bytes(a))); kinds.append(3)
+            elif type(a).__name__ == "CArgObject":              # C.byref(x)
+                words.append(put_blob(bytes(a._obj))); kinds.append(3)
+            elif isinstance(a, C._Pointer):                       # C.cast(device pointer, POINTER(c_float))
+                words.append(C.cast(a, C.c_void_p).value or 0); kinds.append(0)
+            elif isinstance(a, C._SimpleCData):
+                words.append(int(a.value)); kinds.append(0)
+            else:
+                raise MgdError(f"plan: cannot record argument {a!r} of {name}")
+        n = len(words)
+        w = (C.c_int64 * max(1, n))(*[x if x < (1 << 63) else x - (1 << 64) for x in words])
+        k = (C.c_uint8 * max(1, n))(*kinds)
+        raw = bytes(blob)
+        check(load_raw().mgd_plan_add_call(self.handle, name.encode(), w, k, n, raw if raw else None, len(raw)), f"plan_add_call({name})")
+
+    def finish(self):
+        return Plan(self.handle, self.streams, self.nparams)
+
+
+class _RecProxy:
+    """What load() returns while a Recorder is active: every entry point runs as usual and is recorded when it succeeds."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        raw = getattr(self._lib, name)
+        if not name.startswith("mgd_") or name.startswith(("mgd_plan_", "mgd_last_", "mgd_version")) or name.endswith("_workspace_size"):
+            return raw
+
+        def call(*args):
+            rc = raw(*args)
+            rec = RECORDER
+            if rec is not None and rc == 0:
+                try:
+                    rec.add(name, args)
+                except MgdError as e:
+                    rec.error = rec.error or str(e)
+            return rc
+        return call
+
+
+def load_raw():
+    load()
+    return _lib
+
+
 def use_diag():
     """Make this process run on the DIAGNOSTIC library (tools/ only; before the first load()).  It is the same code built with
     -DMGD_DIAG: kernels with ablation switches and stamps, never what a product run measures or ships."""
@@ -139,7 +269,7 @@ def load():
     """Load the shared library (no GPU needed for this; compute calls need one)."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _lib if RECORDER is None else _RecProxy(_lib)
     if not os.path.exists(LIB_PATH):
         raise MgdError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -152,6 +282,12 @@ def load():
                  "mgd_nms_workspace_size", "mgd_wbf_workspace_size", "mgd_letterbox_workspace_size"):
         getattr(lib, name).restype = C.c_size_t
     lib.mgd_latency_workspace_size.restype = C.c_int64
+    lib.mgd_plan_add_call.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.c_int, C.c_char_p, C.c_int64]
+    lib.mgd_plan_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int]
+    lib.mgd_plan_add_wait.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.mgd_plan_destroy.argtypes = [C.c_void_p]
+    lib.mgd_plan_size.argtypes = [C.c_void_p]
+    lib.mgd_memset_async.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
     lib.mgd_conv_wgrad_workspace_size.restype = C.c_int64
     lib.mgd_uncached_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
     lib.mgd_uncached_free.argtypes = [C.c_void_p]

@@ -374,7 +374,7 @@ class Network:
         A = self.arena(B, H, W)
         A["image"] = images
         if self.training:
-            self.stats_all.zero_()              # (a launch of its own: not in front of an inference forward)
+            ops.memset0(self.stats_all)         # (a launch of its own: not in front of an inference forward)
         x = self._conv_bn_act(A, 0, images)
         i = 1
         feats = {}
@@ -444,9 +444,7 @@ class Network:
             if dbias is not None:
                 self.O.bias_grad(dy, dbias)
             return
-        ev = torch.cuda.Event()
-        ev.record()
-        self.wg_stream.wait_event(ev)
+        ops.stream_wait(self.wg_stream)
         with torch.cuda.stream(self.wg_stream):
             self.O.conv_wgrad(x, dy, dw, k, s, **kw)
             if dbias is not None:
@@ -582,10 +580,8 @@ class Network:
                               c0.dbeta, c0.dw)
         else:
             dy0 = self._bwd_bn(A, 0, g)
-            ev = torch.cuda.Event()
-            ev.record()
             side = self.wg_stream if self.overlap_wgrad else torch.cuda.current_stream()
-            side.wait_event(ev)
+            ops.stream_wait(side)
             with torch.cuda.stream(side):
                 self.O.stem_wgrad(A["image"], dy0, c0.dw)       # matrix cores, straight from the fp32 image
         self._join_wgrad()
@@ -594,7 +590,7 @@ class Network:
 
     def _join_wgrad(self):
         if self.overlap_wgrad:
-            torch.cuda.current_stream().wait_stream(self.wg_stream)
+            ops.stream_wait(torch.cuda.current_stream(), self.wg_stream)
 
     def _wire(self, A):
         """Forward input activation of each backbone conv, per arena."""
@@ -615,4 +611,4 @@ class Network:
         A["fin"] = fin
 
     def zero_grad(self):
-        self.grads.zero_()
+        ops.memset0(self.grads)

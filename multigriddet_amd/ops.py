@@ -55,6 +55,25 @@ def _launch_gemm(d, what):
     PROFILE.append((e0, e1, 2.0 * d.N * d.Hg * d.Wg * d.ntaps * d.Ci * d.Co, variant, what, by))
 
 
+def memset0(t):
+    """Zero-fill on the current stream through the library (hipMemsetAsync): part of a recorded launch plan, unlike t.zero_()."""
+    L.check(L.load().mgd_memset_async(L.ptr(t), 0, C.c_int64(t.numel() * t.element_size()), L.stream_ptr()), "memset_async")
+    return t
+
+
+def stream_wait(waiting, signalling=None):
+    """`waiting` (a torch stream) waits for everything enqueued so far on `signalling` (default: the current stream); recorded
+    when a launch plan is being recorded (_lib.Recorder)."""
+    sig = signalling if signalling is not None else torch.cuda.current_stream()
+    if waiting.cuda_stream == sig.cuda_stream:
+        return
+    ev = torch.cuda.Event()
+    ev.record(sig)
+    waiting.wait_event(ev)
+    if L.RECORDER is not None:
+        L.RECORDER.wait(waiting, sig)
+
+
 def _ru(x, m):
     return (x + m - 1) // m * m
 
@@ -513,8 +532,9 @@ def _anchor_array(anchors):
     return a
 
 
-def build_targets(boxes, input_shape, anchors, num_classes, grid_shapes=None, mode=0, return_assignment=False):
-    """boxes: fp32 CUDA [B, M, 5] -> list of fp32 [B, gh, gw, 5+A+C]."""
+def build_targets(boxes, input_shape, anchors, num_classes, grid_shapes=None, mode=0, return_assignment=False, out=None):
+    """boxes: fp32 CUDA [B, M, 5] -> list of fp32 [B, gh, gw, 5+A+C].  out: (ys, workspace) of an earlier call of the same
+    shape - the caller keeps them (a training step's targets always land in the same buffers, train_step.TrainStep)."""
     L.require_gpu()
     lib = L.load()
     B, M, _ = boxes.shape
@@ -525,15 +545,22 @@ def build_targets(boxes, input_shape, anchors, num_classes, grid_shapes=None, mo
         grid_shapes = [(H // s, W // s) for s in (32, 16, 8)][:nl]
     ghw = (C.c_int32 * (2 * nl))(*[int(v) for g in grid_shapes for v in g])
     F = 5 + A + num_classes
-    ys = [torch.empty(B, int(g[0]), int(g[1]), F, dtype=torch.float32, device=boxes.device) for g in grid_shapes]
     need = lib.mgd_build_targets_workspace_size(B, M, nl, ghw)
-    ws = torch.empty(need, dtype=torch.uint8, device=boxes.device)
+    if out is not None:
+        ys, ws = out
+        assert len(ys) == nl and ws.numel() >= need and all(tuple(y.shape) == (B, int(g[0]), int(g[1]), F) for y, g in zip(ys, grid_shapes))
+    else:
+        ys = [torch.empty(B, int(g[0]), int(g[1]), F, dtype=torch.float32, device=boxes.device) for g in grid_shapes]
+        ws = torch.empty(need, dtype=torch.uint8, device=boxes.device)
     assign = torch.empty(B, M, 4, dtype=torch.int32, device=boxes.device) if return_assignment else None
     yp = (C.c_void_p * nl)(*[y.data_ptr() for y in ys])
-    af = a.reshape(-1)
-    L.check(lib.mgd_build_targets(L.ptr(boxes.contiguous()), B, M, af.ctypes.data_as(C.POINTER(C.c_float)), nl, A,
+    af = (C.c_float * a.size)(*[float(v) for v in a.reshape(-1)])      # (a ctypes array: a recorded plan copies it by size)
+    assert boxes.is_contiguous()
+    L.check(lib.mgd_build_targets(L.ptr(boxes), B, M, af, nl, A,
                                   num_classes, H, W, ghw, yp, L.ptr(assign), mode, L.ptr(ws), C.c_size_t(need),
                                   L.stream_ptr()), "build_targets")
+    if out is not None:
+        return ys
     if return_assignment:
         return ys, assign
     return ys

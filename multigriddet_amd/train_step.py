@@ -55,6 +55,10 @@ class TrainStep:
         self.early_optimizer = True     # see _step_body
         self._graphs = {}
         self._hyper = torch.zeros(2, dtype=torch.float32, device=dev)
+        # launch plan (enable_plan): the step's ~600 C-ABI calls recorded once, replayed by mgd_plan_run without the interpreter
+        self.use_plan = False
+        self._plans = {}
+        self._targets = {}
 
     # ------------------------------------------------------------------ helpers
     def _grids(self, H, W):
@@ -78,6 +82,56 @@ class TrainStep:
         eagerly (they size arenas and set kernel attributes), the third is captured.  Adam's bias-corrected step
         size lives in device memory (mgd_adam_step_dev) and is refreshed before every replay."""
         self.use_graph = bool(on)
+
+    def enable_plan(self, on=True):
+        """Replay the step from a recorded LAUNCH PLAN (csrc/plan.cpp): the third step of a new input shape runs eagerly while
+        every call into the library is recorded - entry point, arguments, stream, cross-stream waits; from then on one call,
+        mgd_plan_run, issues the same launches on the same two streams from C with the interpreter lock released (a step costs
+        Python ~6 ms of enqueueing otherwise - time the loader's threads of the same process cannot use).  Not a hipGraph: the
+        streams remain two queues.  Single process, Adam / AdamW (the step size lives in device memory, as under enable_graph);
+        the batch's images / boxes may be new tensors every step (their addresses are parameters of the plan)."""
+        self.use_plan = bool(on)
+        self._plans = {}
+        return self
+
+    def _plannable(self, boxes):
+        return self.use_plan and self.world == 1 and boxes is not None and self.optimizer in ("adam", "adamw") and not self.net.fp32
+
+    def _step_plan(self, images, boxes):
+        from . import _lib as L
+        net = self.net
+        assert images.is_contiguous() and boxes.is_contiguous() and images.dtype == torch.float32 and boxes.dtype == torch.float32
+        key = (tuple(images.shape), tuple(boxes.shape), net.freeze_backbone, net.freeze_all_but_pred, net.freeze_bn)
+        st = self._plans.get(key)
+        if st is None:
+            st = self._plans[key] = {"eager": 0, "plan": None}
+        if st["plan"] is False or (st["plan"] is None and st["eager"] < 2):
+            st["eager"] += 1                              # allocations (arenas, workspaces, kernel attributes) happen here
+            return self._step_eager(images, boxes, None)
+        self.step_count += 1
+        lr_t, lr_wd = self._adam_hyper()
+        self._hyper[0:1].fill_(lr_t)
+        self._hyper[1:2].fill_(lr_wd)
+        cur = torch.cuda.current_stream()
+        self.main_stream.wait_stream(cur)
+        if st["plan"] is None:
+            rec = L.Recorder([self.main_stream, net.wg_stream], params=[images, boxes])
+            L.RECORDER = rec
+            try:
+                with torch.cuda.stream(self.main_stream):
+                    st["comp"] = self._step_body(images, boxes, None, dev_hyper=True)
+            finally:
+                L.RECORDER = None
+            if rec.error is not None:                     # something in this configuration cannot be replayed: stay eager
+                import warnings
+                warnings.warn(f"launch plan not used: {rec.error}")
+                st["plan"] = False
+            else:
+                st["plan"] = rec.finish()
+        else:
+            st["plan"].run([images, boxes])
+        cur.wait_stream(self.main_stream)
+        return st["comp"]
 
     def _graphable(self, boxes):
         return self.use_graph and self.world == 1 and boxes is not None and self.optimizer in ("adam", "adamw")
@@ -119,6 +173,8 @@ class TrainStep:
     def step(self, images, boxes=None, y_true=None):
         """images fp32 CUDA [B,H,W,3] in [0,1]; boxes fp32 CUDA [B,M,5] (x1,y1,x2,y2,cls) or ready y_true.
         Returns the device tensor of 8 loss components (index 7 = total)."""
+        if y_true is None and self._plannable(boxes):
+            return self._step_plan(images, boxes)
         if y_true is None and self._graphable(boxes):
             return self._step_graph(images, boxes)
         return self._step_eager(images, boxes, y_true)
@@ -139,8 +195,16 @@ class TrainStep:
         net = self.net
         B, H, W, _ = images.shape
         if y_true is None:
-            y_true = ops.build_targets(boxes, (H, W), self.anchors, self.num_classes, self._grids(H, W),
-                                       mode=self.target_mode)
+            # the targets of a shape always land in the same buffers (a recorded plan holds their addresses)
+            tkey = (tuple(boxes.shape), H, W)
+            tout = self._targets.get(tkey)
+            if tout is None:
+                ys = ops.build_targets(boxes, (H, W), self.anchors, self.num_classes, self._grids(H, W), mode=self.target_mode)
+                need = ops.L.load().mgd_build_targets_workspace_size(B, boxes.shape[1], len(ys),
+                                                                     (ops.C.c_int32 * (2 * len(ys)))(*[int(v) for g in self._grids(H, W) for v in g]))
+                tout = self._targets[tkey] = (ys, torch.empty(need, dtype=torch.uint8, device=boxes.device))
+            y_true = ops.build_targets(boxes if boxes.is_contiguous() else boxes.contiguous(), (H, W), self.anchors, self.num_classes,
+                                       self._grids(H, W), mode=self.target_mode, out=tout)
         outs = net.forward(images)
         net.zero_grad()
         runner, douts = self._loss_runner(B, H, W)
@@ -170,9 +234,7 @@ class TrainStep:
                 if ld not in EARLY_SPLITS:
                     return
                 k = EARLY_SPLITS.index(ld)
-                ev = torch.cuda.Event()
-                ev.record()
-                net.wg_stream.wait_event(ev)          # BN-affine gradients of these layers come from the main stream
+                ops.stream_wait(net.wg_stream)        # BN-affine gradients of these layers come from the main stream
                 with torch.cuda.stream(net.wg_stream):
                     self._optimizer_range(offs[k], ends[k], dev_hyper)
                     net._pack_seg[k].run()

@@ -307,6 +307,65 @@ def test_graph_replay_matches_eager_step():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("freeze_bn", [True, False])
+def test_launch_plan_replay_matches_eager_step(freeze_bn):
+    """TrainStep.enable_plan(): the step recorded as a launch plan (csrc/plan.cpp: every C-ABI call with its arguments and
+    stream, the cross-stream waits, the buffer clears) and replayed by mgd_plan_run issues the SAME launches as the eager
+    Python path.  Three networks: A steps eagerly, B from its plan, C eagerly again; before every compared step B and C are
+    given A's exact state (weights, BatchNorm moving statistics, Adam moments, step count), so all three compute the same step
+    on fresh input tensors at new addresses (plan parameters).
+    freeze_bn=True (BatchNorm on its moving statistics): the step is deterministic up to the order of the weight gradient's
+    fp32 atomics - loss and full gradient of B must equal A's to 1e-5 / cosine 0.99999.
+    freeze_bn=False (batch statistics): 69 bf16 layers amplify the last-bit noise of the statistics' atomics at random
+    initialisation: two EAGER runs from one state already differ by ~1e-3 in the loss and have a
+    gradient cosine of 0.86 - 0.89 (measured, four networks side by side); B must agree with A within that band, like C."""
+    import torch
+    from multigriddet_amd.engine import Network
+    from multigriddet_amd.train_step import TrainStep
+    import bench
+    dev = torch.device("cuda:0")
+    batches = []
+    for seed in (0, 1):
+        img, bx = bench.synth_batch(seed, 4, 256)
+        batches.append((torch.from_numpy(img).to(dev), torch.from_numpy(bx).to(dev)))
+    nets = [Network(80, 3, dev, seed=0) for _ in range(3)]
+    for n in nets:
+        n.freeze_bn = freeze_bn
+    ta, tb, tc = (TrainStep(n, bench.coco_anchors(), 80, (256, 256), 4, lr=1e-4) for n in nets)
+    tb.enable_plan(True)
+    na, nb, nc = nets
+    for i in range(3):                               # the planned step: two eager steps, then the recording step
+        for t in (ta, tb, tc):
+            t.step(*batches[0])
+    plans = [st["plan"] for st in tb._plans.values()]
+    assert len(plans) == 1 and plans[0] not in (None, False) and plans[0].size > 300, [getattr(p, "size", p) for p in plans]
+    keep = []
+
+    def cosine(x, y):
+        x, y = x.double(), y.double()
+        return float((x * y).sum() / (x.norm() * y.norm()))
+    for i in range(4):
+        torch.cuda.synchronize()
+        for n, t in ((nb, tb), (nc, tc)):
+            n.params.copy_(na.params); n.moving.copy_(na.moving); t.m.copy_(ta.m); t.v.copy_(ta.v)
+            n.refresh_packed()
+            t.step_count = ta.step_count
+        a, b = batches[i % 2]
+        ins = [(a, b), (a.clone(), b.clone()), (a.clone(), b.clone())]      # new addresses every step
+        keep.append(ins)
+        la, lb, lc = (float(t.step(*x)[7]) for t, x in zip((ta, tb, tc), ins))
+        torch.cuda.synchronize()
+        cab, cac = cosine(na.grads, nb.grads), cosine(na.grads, nc.grads)
+        if freeze_bn:
+            assert abs(la - lb) <= 1e-5 * abs(la), (i, la, lb)
+            assert cab > 0.99999, (i, cab, cac)
+        else:
+            assert np.isfinite(lb) and abs(la - lb) <= 5e-3 * abs(la) and abs(la - lc) <= 5e-3 * abs(la), (i, la, lb, lc)
+            assert cab > 0.75 and abs(cab - cac) < 0.1, (i, cab, cac)
+    assert tb.step_count == ta.step_count == 7
+
+
+@pytest.mark.gpu
 def test_multiscale_steps_share_one_network():
     """BASELINE config 3 (multi-scale {320..608}): one Network / TrainStep takes batches of different resolutions step by
     step - every arena, loss configuration and target grid is keyed by the input size, weights and Adam state are shared."""

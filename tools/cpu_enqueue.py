@@ -25,3 +25,17 @@ for _ in range(N):
     net.backward(douts); t4 = time.perf_counter(); acc["backward"] += t4 - t3
     ts.step_count += 1; ts.apply_optimizer(); t5 = time.perf_counter(); acc["opt"] += t5 - t4
 print({k: round(v / N * 1e3, 3) for k, v in acc.items()}, "ms of host time per phase; total", round(sum(acc.values()) / N * 1e3, 3))
+
+# the same step from a recorded launch plan (TrainStep.enable_plan): host time of ONE mgd_plan_run
+ts.enable_plan(True)
+for _ in range(4):
+    ts.step(img, bx)
+torch.cuda.synchronize()
+tp = 0.0
+for _ in range(N):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    ts.step(img, bx)
+    tp += time.perf_counter() - t
+plan = [st["plan"] for st in ts._plans.values()][0]
+print("launch plan:", plan.size if plan else plan, "recorded operations;", round(tp / N * 1e3, 3), "ms of host time per step (no device sync inside)")
