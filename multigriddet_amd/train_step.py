@@ -56,9 +56,11 @@ class TrainStep:
         self._graphs = {}
         self._hyper = torch.zeros(2, dtype=torch.float32, device=dev)
         # launch plan (enable_plan): the step's ~600 C-ABI calls recorded once, replayed by mgd_plan_run without the interpreter
-        self.use_plan = False
+        # (on by default for single-process Adam / AdamW runs; MGD_PLAN=0 or enable_plan(False): every launch from Python)
+        self.use_plan = os.environ.get("MGD_PLAN", "1") == "1"
         self._plans = {}
         self._targets = {}
+        self._ytrue = {}
 
     # ------------------------------------------------------------------ helpers
     def _grids(self, H, W):
@@ -94,32 +96,47 @@ class TrainStep:
         self._plans = {}
         return self
 
-    def _plannable(self, boxes):
-        return self.use_plan and self.world == 1 and boxes is not None and self.optimizer in ("adam", "adamw") and not self.net.fp32
+    def _plannable(self, images, boxes, y_true):
+        if not (self.use_plan and self.world == 1 and self.optimizer in ("adam", "adamw") and not self.net.fp32):
+            return False
+        if ops.PROFILE is not None or (boxes is None) == (y_true is None):      # (per-launch event brackets need the eager path)
+            return False
+        return images.is_contiguous() and images.dtype == torch.float32 and (boxes is None or (boxes.is_contiguous() and boxes.dtype == torch.float32))
 
-    def _step_plan(self, images, boxes):
+    def _step_plan(self, images, boxes, y_true=None):
         from . import _lib as L
         net = self.net
-        assert images.is_contiguous() and boxes.is_contiguous() and images.dtype == torch.float32 and boxes.dtype == torch.float32
-        key = (tuple(images.shape), tuple(boxes.shape), net.freeze_backbone, net.freeze_all_but_pred, net.freeze_bn)
+        key = (tuple(images.shape), tuple(boxes.shape) if boxes is not None else "y_true", net.freeze_backbone, net.freeze_all_but_pred,
+               net.freeze_bn)
         st = self._plans.get(key)
         if st is None:
             st = self._plans[key] = {"eager": 0, "plan": None}
         if st["plan"] is False or (st["plan"] is None and st["eager"] < 2):
             st["eager"] += 1                              # allocations (arenas, workspaces, kernel attributes) happen here
-            return self._step_eager(images, boxes, None)
+            return self._step_eager(images, boxes, y_true)
+        if y_true is not None:
+            # ready targets (the generator's device part built them): they arrive in new tensors every batch, and the loss takes
+            # them through a pointer table - the plan reads them from buffers of its own (three device copies, 43 MB at 608 x 608)
+            yk = tuple(tuple(y.shape) for y in y_true)
+            buf = self._ytrue.get(yk)
+            if buf is None:
+                buf = self._ytrue[yk] = [torch.empty_like(y) for y in y_true]
+            for d, y in zip(buf, y_true):
+                d.copy_(y)
+            y_true = buf
         self.step_count += 1
         lr_t, lr_wd = self._adam_hyper()
         self._hyper[0:1].fill_(lr_t)
         self._hyper[1:2].fill_(lr_wd)
         cur = torch.cuda.current_stream()
         self.main_stream.wait_stream(cur)
+        params = [images] if boxes is None else [images, boxes]
         if st["plan"] is None:
-            rec = L.Recorder([self.main_stream, net.wg_stream], params=[images, boxes])
+            rec = L.Recorder([self.main_stream, net.wg_stream], params=params)
             L.RECORDER = rec
             try:
                 with torch.cuda.stream(self.main_stream):
-                    st["comp"] = self._step_body(images, boxes, None, dev_hyper=True)
+                    st["comp"] = self._step_body(images, boxes, y_true, dev_hyper=True)
             finally:
                 L.RECORDER = None
             if rec.error is not None:                     # something in this configuration cannot be replayed: stay eager
@@ -129,7 +146,7 @@ class TrainStep:
             else:
                 st["plan"] = rec.finish()
         else:
-            st["plan"].run([images, boxes])
+            st["plan"].run(params)
         cur.wait_stream(self.main_stream)
         return st["comp"]
 
@@ -173,8 +190,8 @@ class TrainStep:
     def step(self, images, boxes=None, y_true=None):
         """images fp32 CUDA [B,H,W,3] in [0,1]; boxes fp32 CUDA [B,M,5] (x1,y1,x2,y2,cls) or ready y_true.
         Returns the device tensor of 8 loss components (index 7 = total)."""
-        if y_true is None and self._plannable(boxes):
-            return self._step_plan(images, boxes)
+        if self._plannable(images, boxes, y_true):
+            return self._step_plan(images, boxes, y_true)
         if y_true is None and self._graphable(boxes):
             return self._step_graph(images, boxes)
         return self._step_eager(images, boxes, y_true)

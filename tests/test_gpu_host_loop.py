@@ -438,10 +438,10 @@ def test_prefetching_generator_hides_the_host_path(tmp_path):
     # (2) timing
     dev = torch.device("cuda:0")
     net = Network(80, 3, dev, seed=0)
-    ts = TrainStep(net, anchors, 80, (S, S), B, lr=1e-4)
+    ts = TrainStep(net, anchors, 80, (S, S), B, lr=1e-4).enable_plan(True)
     img, bx = bench.synth_batch(0, B, S)
     img, bx = torch.from_numpy(img).to(dev), torch.from_numpy(bx).to(dev)
-    for _ in range(3):
+    for _ in range(4):
         ts.step(img, bx)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -471,15 +471,16 @@ def test_prefetching_generator_hides_the_host_path(tmp_path):
     gc.collect()                                       # loader processes of generators earlier tests dropped
     gp = gen(4, False)
     epochs(gp, 1)                                      # starts the loader processes, warms the allocator caches
-    # best of three measurements: the host side of a step (600 kernel launches from Python) shares the interpreter lock and
-    # the box's 16 cores with the loader's threads and processes, and a shared CI box adds its own noise
-    t_pre = min(epochs(gp, 2) for _ in range(3))
+    t_pre = epochs(gp, 3)                              # ONE measurement
     gp.close()
     t_sync = epochs(gen(0, False), 2)
-    print(f"\nstep: synthetic {t_syn * 1e3:.2f} ms, prefetching loader {t_pre * 1e3:.2f} ms (best of 3), synchronous loader "
+    print(f"\nstep: synthetic {t_syn * 1e3:.2f} ms, prefetching loader {t_pre * 1e3:.2f} ms, synchronous loader "
           f"{t_sync * 1e3:.2f} ms; host alone {t_host * 1e3:.2f} ms per batch ({nw} threads)")
+    assert any(p not in (None, False) for p in (st["plan"] for st in ts._plans.values()))      # the steps ran from plans
     if t_host <= 0.8 * t_syn:
-        assert t_pre <= 1.10 * t_syn, (t_pre, t_syn, t_host)
+        assert t_pre <= 1.05 * t_syn, (t_pre, t_syn, t_host)
     else:
         assert t_pre <= 1.15 * max(t_host, t_syn), (t_pre, t_syn, t_host)
-    assert t_pre < 0.9 * t_sync or t_sync <= 1.10 * t_syn
+    # and it hides at least half of what the synchronous path adds to a step (with the plan's 1.3 ms of host time per step the
+    # synchronous path itself costs little more than the host's decode time beyond the GPU's)
+    assert t_pre < t_sync and (t_pre - t_syn) <= 0.5 * (t_sync - t_syn) or t_sync <= 1.05 * t_syn, (t_pre, t_sync, t_syn)
