@@ -974,6 +974,7 @@ extern "C" int mgd_conv_wgrad(const mgd_wgrad_desc* d, void* stream) {
     const bool want_row = form == MGD_WGRAD_AUTO && can_row && std9 && co >= 128 && ci >= 64 && d->partial &&
                           (long long)a.P * row_tiles >= 256ll * 1500 && d->partial_bytes >= mgd_conv_wgrad_workspace_size(d);
     if (form == MGD_WGRAD_ROW || want_row) {
+      a.splits = d->form_arg;                     // kernel-row form: form_arg = cap on its blocks (0: 256, one per CU)
       MGD_REQUIRE(mgd::launch_wgrad5(a, st) == MGD_OK, "wgrad: the kernel-row form refused the geometry");
       MGD_CHECK_LAUNCH("conv_wgrad(kernel row)");
       return MGD_OK;

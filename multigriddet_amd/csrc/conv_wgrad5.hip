@@ -317,7 +317,10 @@ bool wgrad5_plan(WgradArgs& a) {
   a.tilesCo = cdiv(a.Co, 128);
   a.tilesCi = cdiv(a.Ci, 128);
   const int tiles = a.tilesCo * a.tilesCi * (a.ntaps == 9 ? 3 : 1);
-  int splits = 256 / tiles;                                    // one block per CU, one round
+  // one block per CU, one round; a.splits > 0: the caller's cap on the number of blocks (a launch that shares the chip with
+  // another stream leaves CUs free: a block holds every register of its CU)
+  const int cap = a.splits > 0 && a.splits < 256 ? a.splits : 256;
+  int splits = cap / tiles;
   if (splits < 1) splits = 1;
   a.chunk = cdiv(cdiv(a.P, splits), 4 * W5_KP) * 4 * W5_KP;    // about whole ring revolutions of K-steps
   a.splits = cdiv(a.P, a.chunk);

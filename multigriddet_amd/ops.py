@@ -348,6 +348,11 @@ _WGRAD_BLOCKS = int(os.environ.get("MGD_WGRAD_BLOCKS", "0"))      # 0: by tile s
 WGRAD_ROW_FORM = os.environ.get("MGD_WGRAD_ROW", "1") == "1"      # engine: give the kernel-row form its slab workspace (0: never dispatched)
 WGRAD_FORM = int(os.environ.get("MGD_WGRAD_FORM", "0"))
 WGRAD_FORM_ARG = int(os.environ.get("MGD_WGRAD_FORM_ARG", "0"))
+# Blocks of a kernel-row weight-gradient launch under the library's own dispatch.  One of its blocks holds every register of a CU,
+# and in the step the weight gradients run on a side stream UNDER the data-gradient / BatchNorm chain: with 256 blocks the chain's
+# kernels find no CU (same-box A/B of bench.py: 12.38 ms per step at 256 blocks, 12.12 at 192, 12.12 at 128, 12.16 at 96;
+# 12.46 without the form).  Alone a launch is fastest at 256 (tools/bench_wgrad_forms.py sets it).
+WGRAD_ROW_BLOCKS = int(os.environ.get("MGD_WGRAD_ROW_BLOCKS", "128"))
 
 
 def wgrad_splits(P, co, ci, T, target_blocks=None):
@@ -391,7 +396,7 @@ def conv_wgrad(x, dy, dw, k, s, splits=None, ws=None):
     for i, (a, b) in enumerate(zip(dh, dwo)):
         d.dh[i], d.dw_off[i] = a, b
     d.splits = splits if splits is not None else wgrad_splits(N * Ho * Wo, Co, Ci, k * k)
-    d.form, d.form_arg = WGRAD_FORM, WGRAD_FORM_ARG
+    d.form, d.form_arg = WGRAD_FORM, (WGRAD_FORM_ARG if WGRAD_FORM else WGRAD_ROW_BLOCKS)
     if ws is not None:
         d.partial, d.partial_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     if PROFILE is None:

@@ -20,6 +20,7 @@ def main():
     forms = [tuple(int(v) for v in f.split(":")) for f in sys.argv[1:]] or [(0, 0), (5, 0), (5, 1)]   # 5:1 = kernel-row form with slabs
     B, rounds, iters = 16, 5, 5
     dev = torch.device("cuda:0")
+    ops.WGRAD_ROW_BLOCKS = 0                           # each launch alone: one block per CU
     global WS
     WS = torch.empty(64 << 20, dtype=torch.float32, device=dev)      # 256 MB: slabs of the kernel-row form
     print("layer                 " + "  ".join(f"{f[0]:>2}:{f[1]}     us  TF/s  reldiff" for f in forms))
