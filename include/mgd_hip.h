@@ -122,6 +122,12 @@ enum {
 
 int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream);
 
+/* n = 2..4 descriptors of ONE geometry that differ in wpk, K_pad, the taps and the output offset only - the four output-parity
+ * classes of a stride-2 data gradient (ZeroPadding2D + 'valid' stride-2 conv, models/backbones/darknet.py:33-34) - in ONE
+ * launch: a block works on class (block / tiles).  128-channel weight tiles, Ci % 64 == 0, bf16 output, library dispatch;
+ * MGD_EINVAL otherwise (launch the classes one by one with mgd_conv_gather_gemm). */
+int mgd_conv_gather_gemm_classes(const mgd_conv_desc* d, int n, void* stream);
+
 /* Workspace of the latency form with K ranges (mgd_conv_desc.latency, splitk > 1).  Partial tiles written by blocks on one
  * XCD are read by a block on another inside the same kernel, which ordinary (L2-cached) device memory does not guarantee, so
  * the workspace is UNCACHED device memory - and it is the CALLER's: the library keeps no buffer and no other state, so two

@@ -106,7 +106,7 @@ class DecodeCfg(C.Structure):
 
 # every symbol include/mgd_hip.h declares
 EXPORTS = [
-    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_plan_create", "mgd_plan_destroy", "mgd_plan_size", "mgd_plan_add_call", "mgd_plan_add_wait", "mgd_plan_run", "mgd_memset_async", "mgd_latency_workspace_size", "mgd_uncached_alloc", "mgd_uncached_free", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_conv_wgrad_workspace_size", "mgd_stem_fwd", "mgd_stem_fwd_act", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
+    "mgd_last_error", "mgd_version", "mgd_last_kernel", "mgd_plan_create", "mgd_plan_destroy", "mgd_plan_size", "mgd_plan_add_call", "mgd_plan_add_wait", "mgd_plan_run", "mgd_memset_async", "mgd_latency_workspace_size", "mgd_uncached_alloc", "mgd_uncached_free", "mgd_latency_tickets", "mgd_conv_gather_gemm", "mgd_conv_gather_gemm_classes", "mgd_conv_dgrad_s2_patch", "mgd_conv_wgrad", "mgd_conv_wgrad_workspace_size", "mgd_stem_fwd", "mgd_stem_fwd_act", "mgd_stem_wgrad", "mgd_stem_wgrad_bn",
     "mgd_pack_weights", "mgd_pack_weights_batch", "mgd_stem_im2col", "mgd_bn_finalize", "mgd_bn_act_fwd", "mgd_bn_act_fwd_fused", "mgd_bn_act_bwd_reduce", "mgd_bn_act_bwd_apply",
     "mgd_upsample_concat_fwd", "mgd_upsample_concat_bwd", "mgd_bias_grad", "mgd_f32_to_bf16", "mgd_bf16_to_f32",
     "mgd_adam_step", "mgd_adam_step_dev", "mgd_sgd_step", "mgd_build_targets_workspace_size", "mgd_build_targets",

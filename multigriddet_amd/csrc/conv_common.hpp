@@ -53,6 +53,13 @@ struct GemmArgs {
   long long slab_elems;        //   (float*)dst + range * slab_elems
   float* partial;              // conv_gemm11_kernel: fp32 partial tiles [range][tile][128 x 64 in fragment order]
   unsigned* tickets;           //   and one arrival counter per tile (zero between launches)
+  // conv_gemm8_kernel, ncls > 1: ONE launch over several tap classes of one geometry (the four output-parity classes of a
+  // stride-2 data gradient): block b works on class b / nblk with that class's packed image, taps and output offset
+  int ncls;
+  const bf16_t* c_wpk[4];
+  unsigned long long c_tapcode[4];
+  int c_K_pad[4], c_ntaps[4], c_off_h[4], c_off_w[4];
+  unsigned c_rowmask[4], c_colmask[4];
 };
 
 struct WgradArgs {

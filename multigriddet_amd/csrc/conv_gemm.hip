@@ -467,7 +467,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / WP, wp = wave % WP;
-  const int L = xcd_remap((int)blockIdx.x, a.nblk);
+  int bid = (int)blockIdx.x;
+  if (a.ncls > 1) {                                   // tap classes in one launch: this block's class (wave-uniform)
+    const int cls = bid / a.nblk;
+    bid -= cls * a.nblk;
+    // (static indices + selects: a runtime index into the by-value argument block sends the whole block to scratch memory -
+    // 424 bytes per lane and 15 % of the step, measured)
+#define MGD_PICK(f) (cls == 0 ? a.f[0] : cls == 1 ? a.f[1] : cls == 2 ? a.f[2] : a.f[3])
+    a.wpk = MGD_PICK(c_wpk); a.tapcode = MGD_PICK(c_tapcode); a.K_pad = MGD_PICK(c_K_pad); a.ntaps = MGD_PICK(c_ntaps);
+    a.out_off_h = MGD_PICK(c_off_h); a.out_off_w = MGD_PICK(c_off_w); a.rowmask = MGD_PICK(c_rowmask); a.colmask = MGD_PICK(c_colmask);
+#undef MGD_PICK
+  }
+  const int L = xcd_remap(bid, a.nblk);
   const int tc = L % a.tilesC, tp = L / a.tilesC;
   const int co0 = tc * BNC, pix0 = tp * BMP;
   if (ABL && (a.dbg & 1024)) return;                  // dispatch cost alone
@@ -635,7 +646,7 @@ int launch_gemm8(GemmArgs& a, hipStream_t st) {
   a.nblk = a.tilesC * cdiv(a.M, 128);
   size_t ring = (size_t)NST * 128 * ROWB;
   size_t epi = a.dst_f32 ? (size_t)128 * (128 * 4 + 16) : (size_t)128 * (128 * 2 + 16) + 4 * 2 * 128 * 4;
-  const int grid8 = a.nblk;
+  const int grid8 = a.nblk * (a.ncls > 1 ? a.ncls : 1);
   a.aux = (int)(ring > epi ? ring : epi);
   size_t lds = (size_t)a.aux + 128 * 16 + 64;
   auto k = conv_gemm8_kernel<NST, WPE, false, WC, UNI>;
@@ -1567,7 +1578,8 @@ static int counted_tile(const mgd_conv_desc* d, int M, int nt_forced) {
   return nt;
 }
 
-extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
+// validation of a descriptor and its translation into the kernels' argument block
+static int conv_args(const mgd_conv_desc* d, GemmArgs& a) {
   MGD_REQUIRE(d && d->src && d->wpk && d->dst, "conv: null pointer");
   MGD_REQUIRE(d->Ci % 8 == 0 && d->Ci >= 8, "conv: Ci=%d must be a multiple of 8", d->Ci);
   MGD_REQUIRE(d->Co % 8 == 0, "conv: Co=%d must be a multiple of 8", d->Co);
@@ -1581,7 +1593,6 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   MGD_REQUIRE((long long)d->N * d->Hg * d->Wg < (1ll << 31), "conv: too many pixels");
   MGD_REQUIRE(d->splitk <= 1 || d->latency, "conv: K ranges (splitk) exist in the latency form only");
   bool ok;
-  GemmArgs a;
   a.src = (const bf16_t*)d->src; a.wpk = (const bf16_t*)d->wpk; a.dst = d->dst; a.bias = d->bias;
   a.addend = (const bf16_t*)d->addend; a.stats = d->stats;
   a.N = d->N; a.Hs = d->Hs; a.Ws = d->Ws; a.Ci = d->Ci; a.Hg = d->Hg; a.Wg = d->Wg; a.Hd = d->Hd; a.Wd = d->Wd;
@@ -1608,6 +1619,13 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   MGD_REQUIRE((long long)d->N * d->Hs * d->Ws * d->Ci * 2 < (1ll << 32), "conv: source tensor exceeds 32-bit byte addressing (N*Hs*Ws*Ci*2 >= 4 GiB)");
   MGD_REQUIRE((long long)d->Co_pad * d->K_pad * 2 < (1ll << 32), "conv: packed weights exceed 32-bit byte addressing");
 
+  a.ncls = 0;
+  return MGD_OK;
+}
+
+extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
+  GemmArgs a;
+  { const int rc = conv_args(d, a); if (rc != MGD_OK) return rc; }
   hipStream_t st = (hipStream_t)stream;
   const int nk = d->K_pad / BK;
   const int form = d->form;                       // 0: the rules below; anything else: that form or MGD_EINVAL
@@ -1748,6 +1766,41 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   if (uni && !(form == MGD_CONV_GLOBALW && d->form_arg == 1) && !MGD_DBG(a, 0xFE1)) launch_gemm8<2, 3, 4, true>(a, st);
   else launch_gemm8<2, 3, 4>(a, st);
   MGD_CHECK_LAUNCH("conv_gather_gemm(global weight fragments)");
+  return MGD_OK;
+}
+
+// Several tap classes of ONE geometry in one launch (see GemmArgs::ncls): the descriptors may differ in wpk, K_pad, the taps
+// and the output offset only.  Runs on conv_gemm8_kernel (128-channel tiles, wave-uniform K-steps); anything else: MGD_EINVAL,
+// the caller launches the classes one by one.  The class with the longest contraction goes first (it ends last).
+extern "C" int mgd_conv_gather_gemm_classes(const mgd_conv_desc* d, int n, void* stream) {
+  MGD_REQUIRE(d && n >= 2 && n <= 4, "conv classes: 2 to 4 descriptors");
+  GemmArgs a[4];
+  for (int c = 0; c < n; ++c) { const int rc = conv_args(d + c, a[c]); if (rc != MGD_OK) return rc; }
+  const mgd_conv_desc& r = d[0];
+  MGD_REQUIRE(r.Co_pad % 128 == 0 && r.Ci % 64 == 0 && !r.dst_f32 && !r.latency && r.form == MGD_CONV_AUTO,
+              "conv classes: 128-channel weight tiles, Ci %% 64 == 0, bf16 output, library dispatch");
+  for (int c = 1; c < n; ++c) {
+    const mgd_conv_desc& q = d[c];
+    MGD_REQUIRE(q.src == r.src && q.dst == r.dst && q.bias == r.bias && q.addend == r.addend && q.stats == r.stats && q.N == r.N &&
+                    q.Hs == r.Hs && q.Ws == r.Ws && q.Ci == r.Ci && q.Hg == r.Hg && q.Wg == r.Wg && q.Hd == r.Hd && q.Wd == r.Wd &&
+                    q.Co == r.Co && q.in_stride == r.in_stride && q.out_stride == r.out_stride && q.Co_pad == r.Co_pad &&
+                    q.dst_f32 == r.dst_f32 && q.stats_replicas == r.stats_replicas && q.bn_y == r.bn_y && q.bn_sums == r.bn_sums &&
+                    q.act_slope == r.act_slope && !q.latency && q.form == MGD_CONV_AUTO,
+                "conv classes: descriptor %d differs from descriptor 0 in more than weights / taps / output offset", c);
+  }
+  int order[4] = {0, 1, 2, 3};
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j)
+      if (d[order[j]].K_pad > d[order[i]].K_pad) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+  GemmArgs g = a[order[0]];
+  g.ncls = n;
+  for (int c = 0; c < n; ++c) {
+    const GemmArgs& s = a[order[c]];
+    g.c_wpk[c] = s.wpk; g.c_tapcode[c] = s.tapcode; g.c_K_pad[c] = s.K_pad; g.c_ntaps[c] = s.ntaps;
+    g.c_off_h[c] = s.out_off_h; g.c_off_w[c] = s.out_off_w; g.c_rowmask[c] = s.rowmask; g.c_colmask[c] = s.colmask;
+  }
+  launch_gemm8<2, 3, 4, true>(g, (hipStream_t)stream);
+  MGD_CHECK_LAUNCH("conv_gather_gemm(global weight fragments, tap classes)");
   return MGD_OK;
 }
 

@@ -77,7 +77,7 @@ struct Entry {
 #define E(fn) {#fn, &tramp<&fn>::call, tramp<&fn>::nargs}
 // every int-returning, stream-taking entry point of include/mgd_hip.h that a training / inference step may issue
 const Entry kTable[] = {
-    E(mgd_conv_gather_gemm), E(mgd_conv_dgrad_s2_patch), E(mgd_conv_wgrad), E(mgd_stem_fwd), E(mgd_stem_fwd_act), E(mgd_stem_wgrad),
+    E(mgd_conv_gather_gemm), E(mgd_conv_gather_gemm_classes), E(mgd_conv_dgrad_s2_patch), E(mgd_conv_wgrad), E(mgd_stem_fwd), E(mgd_stem_fwd_act), E(mgd_stem_wgrad),
     E(mgd_stem_wgrad_bn), E(mgd_pack_weights), E(mgd_pack_weights_batch), E(mgd_stem_im2col), E(mgd_bn_finalize), E(mgd_bn_act_fwd),
     E(mgd_bn_act_fwd_fused), E(mgd_bn_act_bwd_reduce), E(mgd_bn_act_bwd_apply), E(mgd_upsample_concat_fwd), E(mgd_upsample_concat_bwd),
     E(mgd_bias_grad), E(mgd_f32_to_bf16), E(mgd_bf16_to_f32), E(mgd_adam_step), E(mgd_adam_step_dev), E(mgd_sgd_step),

@@ -335,14 +335,32 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
             d.bn_slope = LEAKY_SLOPE
         L.check(lib.mgd_conv_dgrad_s2_patch(C.byref(d), L.stream_ptr()), "conv_dgrad_s2_patch")
     else:
-        for img, kp, cp, _, (ph, pw, tp) in pk.dgrad:
-            d = _desc(dy, img, out, N, Ho, Wo, Co, H // 2, W // 2, H, W, pk.ci, 1, 2, (ph, pw),
-                      [t[0] for t in tp], [t[1] for t in tp], kp, cp, addend=addend, bnred=bnred)
-            _launch_gemm(d, "conv_dgrad_s2")
+        descs = [_desc(dy, img, out, N, Ho, Wo, Co, H // 2, W // 2, H, W, pk.ci, 1, 2, (ph, pw),
+                       [t[0] for t in tp], [t[1] for t in tp], kp, cp, addend=addend, bnred=bnred)
+                 for img, kp, cp, _, (ph, pw, tp) in pk.dgrad]
+        if S2_CLASSES and descs[0].Co_pad % 128 == 0 and Co % 64 == 0 and not CONV_FORM:
+            # the four output-parity classes in ONE launch (mgd_conv_gather_gemm_classes)
+            arr = (L.ConvDesc * 4)(*descs)
+            if PROFILE is None:
+                L.check(lib.mgd_conv_gather_gemm_classes(arr, 4, L.stream_ptr()), "conv_dgrad_s2")
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                L.check(lib.mgd_conv_gather_gemm_classes(arr, 4, L.stream_ptr()), "conv_dgrad_s2")
+                e1.record()
+                d0 = descs[0]
+                fl = sum(2.0 * d.N * d.Hg * d.Wg * d.ntaps * d.Ci * d.Co for d in descs)
+                nd = d0.N * d0.Hd * d0.Wd * d0.Co
+                by = 2.0 * d0.N * d0.Hs * d0.Ws * d0.Ci + sum(2.0 * d.Co_pad * d.K_pad for d in descs) + 2.0 * nd * (1 + (addend is not None) + (bnred is not None))
+                PROFILE.append((e0, e1, fl, lib.mgd_last_kernel().decode(), "conv_dgrad_s2", by))
+        else:
+            for d in descs:
+                _launch_gemm(d, "conv_dgrad_s2")
     return out
 
 
 _S2_PATCH = os.environ.get("MGD_S2_PATCH", "1") != "0"
+S2_CLASSES = os.environ.get("MGD_S2_CLASSES", "1") != "0"      # stride-2 data gradient: the four parity classes in one launch
 _WGRAD_BLOCKS = int(os.environ.get("MGD_WGRAD_BLOCKS", "0"))      # 0: by tile shape
 # kernel form of the weight-gradient launches (mgd_wgrad_desc.form / form_arg; 0 = the library's dispatch): tests and tools
 WGRAD_ROW_FORM = os.environ.get("MGD_WGRAD_ROW", "1") == "1"      # engine: give the kernel-row form its slab workspace (0: never dispatched)

@@ -379,6 +379,42 @@ def test_conv_latency_form_matches_reference(dev, N, H, W, Ci, Co, k, s, cap, ra
     ws.close()
 
 
+@pytest.mark.parametrize("N,H,W,Ci,Co", [(2, 24, 24, 128, 256), (16, 38, 38, 256, 512), (3, 20, 28, 128, 128)])
+def test_stride2_dgrad_classes_in_one_launch(dev, N, H, W, Ci, Co, monkeypatch):
+    """mgd_conv_gather_gemm_classes: the four output-parity classes of a stride-2 data gradient in ONE launch (a block works on
+    class block / tiles) give exactly the tensor of four separate launches - every output pixel belongs to one class and is
+    computed by the same kernel in the same K order - and the same fused BatchNorm-backward sums up to the order of their
+    atomics; both equal the transposed-convolution reference."""
+    import torch.nn.functional as F
+    from multigriddet_amd import ops
+    g = torch.Generator().manual_seed(9 + Ci + Co)
+    w = torch.randn(Co, 9, Ci, generator=g) / (3 * Ci ** 0.5)
+    pk = ops.PackedConv(Co, Ci, 3, 2, dev)
+    pk.refresh(w.to(dev))
+    dy = bf(torch.randn(N, H // 2, W // 2, Co, generator=g))
+    add = bf(torch.randn(N, H, W, Ci, generator=g))
+    yprev = bf(torch.randn(N, H, W, Ci, generator=g))
+    sc, sh = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+    mu, iv = torch.randn(Ci, generator=g) * 0.2, torch.rand(Ci, generator=g) + 0.5
+    outs, sums = [], []
+    for one in (False, True):
+        monkeypatch.setattr(ops, "S2_CLASSES", one)
+        sm = torch.zeros(ops.STATS_REPLICAS, 2, Ci, device=dev)
+        bnred = tuple(t.to(dev) for t in (yprev.to(torch.bfloat16), sc, sh, mu, iv)) + (sm,)
+        outs.append(ops.conv_dgrad(dy.to(dev), pk, (H, W), addend=add.to(dev), bnred=bnred))
+        fam = ops.L.load().mgd_last_kernel()
+        assert (b"tap classes" in fam) == one, fam
+        sums.append(sm.sum(0))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert torch.allclose(sums[0], sums[1], rtol=1e-4, atol=1e-2)
+    wr = bf(w).view(Co, 3, 3, Ci).permute(0, 3, 1, 2)
+    xp = F.conv_transpose2d(dy.permute(0, 3, 1, 2), wr, stride=2)          # [N, Ci, H+1, W+1] on the top/left-padded grid
+    ref = xp[:, :, 1:H + 1, 1:W + 1].permute(0, 2, 3, 1) + add
+    err = (outs[1].float().cpu() - ref).abs().max().item()
+    assert err <= 0.02 * ref.abs().max().item() + 1e-3, err
+
+
 @pytest.mark.parametrize("N,H,W,Ci,Co,k,s", [(2, 20, 20, 64, 128, 3, 1), (2, 24, 24, 32, 64, 3, 2), (3, 19, 19, 256, 128, 1, 1),
                                              (2, 44, 36, 32, 64, 3, 1)])      # patch-form data gradient (64 -> 32)
 def test_dgrad_fused_bn_reduction(dev, N, H, W, Ci, Co, k, s):
