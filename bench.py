@@ -148,10 +148,12 @@ def infer_bench(dev, size, steps=20, warmup=3):
 def per_layer_bench(dev, size, batch, iters=5):
     """north_star's "fraction of the conv-MFMA roofline on backbone 3x3 convs", from the driver's own run: every distinct
     3x3 convolution of the backbone at the benchmark shape, forward / data gradient / weight gradient each launched ALONE
-    (HIP events around `iters` launches, one warm-up), as TFLOP/s and as a fraction of the dense bf16 peak."""
+    (HIP events around `iters` launches, one warm-up), as TFLOP/s and as a fraction of the dense bf16 peak.  The weight gradient
+    gets the engine's slab workspace and, being alone, one block per CU (inside the step it is capped at ops.WGRAD_ROW_BLOCKS)."""
     from multigriddet_amd import ops
     rows = []
     h = size
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=dev)      # slab workspace of the kernel-row weight gradient
     for f in (64, 128, 256, 512, 1024):
         for (ci, co, s, hin, count) in ((f // 2, f, 2, h, 1), (f // 2, f, 1, h // 2, {64: 1, 128: 2, 256: 8, 512: 8, 1024: 4}[f])):
             ho = hin // s
@@ -178,7 +180,7 @@ def per_layer_bench(dev, size, batch, iters=5):
                 return e0.elapsed_time(e1) * 1e-3 / iters
             tf = [fl / t(fn) / 1e12 for fn in (lambda: ops.conv_fwd(x, pk, out=y, stats=st),
                                                lambda: ops.conv_dgrad(dy, pk, (hin, hin), out=dx),
-                                               lambda: ops.conv_wgrad(x, dy, dw, 3, s))]
+                                               lambda: ops.conv_wgrad(x, dy, dw, 3, s, ws=ws, row_blocks=0))]
             rows.append({"layer": f"{ci}->{co} 3x3 s{s} @{hin}", "count": count, "gflop": round(fl / 1e9, 2),
                          "fwd_tflops": round(tf[0], 1), "dgrad_tflops": round(tf[1], 1), "wgrad_tflops": round(tf[2], 1),
                          "fwd_frac": round(tf[0] / PEAK_BF16_TFLOPS, 3), "dgrad_frac": round(tf[1] / PEAK_BF16_TFLOPS, 3),

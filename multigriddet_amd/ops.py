@@ -400,9 +400,10 @@ def wgrad_splits(P, co, ci, T, target_blocks=None):
     return best
 
 
-def conv_wgrad(x, dy, dw, k, s, splits=None, ws=None):
+def conv_wgrad(x, dy, dw, k, s, splits=None, ws=None, row_blocks=None):
     """dw (fp32 [Co, k*k, Ci]) += x (*) dy.  ws: optional fp32 workspace tensor of the caller (one per stream) for the
-    kernel-row form's per-split slabs (mgd_wgrad_desc.partial)."""
+    kernel-row form's per-split slabs (mgd_wgrad_desc.partial).  row_blocks: block cap of a kernel-row launch (None:
+    WGRAD_ROW_BLOCKS, the in-step value; 0: one block per CU, the fastest for a launch running alone)."""
     N, H, W, Ci = x.shape
     _, Ho, Wo, Co = dy.shape
     d = L.WgradDesc()
@@ -414,7 +415,7 @@ def conv_wgrad(x, dy, dw, k, s, splits=None, ws=None):
     for i, (a, b) in enumerate(zip(dh, dwo)):
         d.dh[i], d.dw_off[i] = a, b
     d.splits = splits if splits is not None else wgrad_splits(N * Ho * Wo, Co, Ci, k * k)
-    d.form, d.form_arg = WGRAD_FORM, (WGRAD_FORM_ARG if WGRAD_FORM else WGRAD_ROW_BLOCKS)
+    d.form, d.form_arg = WGRAD_FORM, (WGRAD_FORM_ARG if WGRAD_FORM else (WGRAD_ROW_BLOCKS if row_blocks is None else row_blocks))
     if ws is not None:
         d.partial, d.partial_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     if PROFILE is None:

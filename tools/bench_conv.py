@@ -58,6 +58,7 @@ def main():
         key = (sp["cin"], sp["cout"], sp["k"], sp["s"], h)
         seen[key] = seen.get(key, 0) + 1
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=dev)       # slab workspace of the kernel-row weight gradient
     totf = 0.0
     print(f"{'cin':>5} {'cout':>5} k s {'H':>4} {'n':>2} | {'fwd us':>8} {'TF/s':>6} {'GB/s':>6} | {'dgrad us':>8} {'TF/s':>6} | {'wgrad us':>8} {'TF/s':>6}")
     for (ci, co, k, s, h), n in seen.items():
@@ -75,7 +76,7 @@ def main():
         skip = os.environ.get("BENCH_SKIP", "")       # e.g. "wgrad" or "fwd,dgrad": passes not to time (reported as 1 us)
         t_f = timeit(lambda: ops.conv_fwd(x, pk, out=y, stats=stats)) if "fwd" not in skip else 1.0
         t_d = timeit(lambda: ops.conv_dgrad(dy, pk, (h, h), out=dx)) if "dgrad" not in skip else 1.0
-        t_w = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s)) if "wgrad" not in skip else 1.0
+        t_w = timeit(lambda: ops.conv_wgrad(x, dy, dw, k, s, ws=ws, row_blocks=0)) if "wgrad" not in skip else 1.0
         by = 2.0 * (x.numel() + y.numel())
         print(f"{ci:5d} {co:5d} {k} {s} {h:4d} {n:2d} | {t_f:8.1f} {fl / t_f / 1e6:6.0f} {by / t_f / 1e3:6.0f} | "
               f"{t_d:8.1f} {fl / t_d / 1e6:6.0f} | {t_w:8.1f} {fl / t_w / 1e6:6.0f}", flush=True)
