@@ -15,16 +15,16 @@ namespace {
 __device__ __forceinline__ void fold_replicas(const float* base, int R, int C, int c, float& s0, float& s1) {
   s0 = 0.f;
   s1 = 0.f;
-  for (int r0 = 0; r0 < R; r0 += 8) {
-    float a[8], b[8];
+  for (int r0 = 0; r0 < R; r0 += 16) {        // 16 replicas (the engine's count) = 32 loads in flight, ONE round trip
+    float a[16], b[16];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 16; ++j) {
       const bool ok = r0 + j < R;
       a[j] = ok ? base[((long long)(r0 + j) * 2 + 0) * C + c] : 0.f;
       b[j] = ok ? base[((long long)(r0 + j) * 2 + 1) * C + c] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 16; ++j) {
       if (r0 + j < R) { s0 += a[j]; s1 += b[j]; }
     }
   }
@@ -112,9 +112,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_fused_kernel(const float* __re
   // dependent round trips (replicas -> barrier -> parameters) that the data loads do not depend on, and a small layer
   // is one tile per thread - so its launch costs one memory round trip instead of three (it matters most inside the
   // backward pass, where the weight-gradient stream multiplies the latency of every round trip).
+  // A block owns CONTIGUOUS chunks of PL * U pixels (consecutive blocks sweep memory in address order, like a copy).
   constexpr int U = 4;
-  const long long stride = (long long)gridDim.x * PL;
-  const long long pstart = (long long)blockIdx.x * PL + pl;
+  const long long stride = PL;
+  const long long pstart = (long long)blockIdx.x * PL * U + pl;
+  const long long pstep = (long long)gridDim.x * PL * U;
   uint4 yv[U], rv[U];
   auto fetch = [&](long long p0) {
 #pragma unroll
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_fused_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = prm[0][lo + j]; sh[j] = prm[1][lo + j]; }
   }
-  for (long long p0 = pstart; p0 < P; p0 += stride * U) {
+  for (long long p0 = pstart; p0 < P; p0 += pstep) {
     if (p0 != pstart) fetch(p0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -220,8 +222,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
   const bool active = oct < CV && pl < PL;
   // first tile and per-channel parameters requested before the replica fold (see bn_act_fwd_fused_kernel)
   constexpr int U = 4;                        // pixels in flight per thread: 8 x 16-byte loads before any use
-  const long long stride = (long long)gridDim.x * PL;
-  const long long pstart = (long long)blockIdx.x * PL + pl;
+  const long long stride = PL;                // contiguous chunks of PL * U pixels per block (see bn_act_fwd_fused_kernel)
+  const long long pstart = (long long)blockIdx.x * PL * U + pl;
+  const long long pstep = (long long)gridDim.x * PL * U;
   uint4 gv[U], yv[U];
   auto fetch = [&](long long p0) {
 #pragma unroll
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
   if (active) {
-    for (long long p0 = pstart; p0 < P; p0 += stride * U) {
+    for (long long p0 = pstart; p0 < P; p0 += pstep) {
       if (p0 != pstart) fetch(p0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -510,9 +513,16 @@ extern "C" int mgd_bn_act_fwd(const void* y, const float* scale, const float* sh
 static void bn_bwd_grid(int64_t P, int C, int* gx, int* gy) {
   int CV = C / 8, CVB = CV < 32 ? CV : 32, PL = 256 / CVB;
   *gy = cdiv(CV, 32);
-  long long g = (P + (long long)PL * 8 - 1) / ((long long)PL * 8);   // >= 8 pixels per thread
-  long long cap = 256 * 8 / *gy;
-  if (g > cap) g = cap;
+  // chunks of PL * 4 pixels (one memory round trip per thread); small tensors: one chunk per block, else every block the
+  // same number (>= 2) of chunks with at most 8 blocks per CU
+  const long long chunks = (P + (long long)PL * 4 - 1) / ((long long)PL * 4);
+  const long long cap = 256 * 8 / *gy;
+  long long g = chunks;
+  if (chunks > cap / 2) {
+    long long iters = (chunks + cap - 1) / cap;
+    if (iters < 2) iters = 2;
+    g = (chunks + iters - 1) / iters;
+  }
   if (g < 1) g = 1;
   *gx = (int)g;
 }

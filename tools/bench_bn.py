@@ -38,6 +38,11 @@ for (P, C), n in seen.items():
     t_r = timeit(lambda: L.check(lib.mgd_bn_act_bwd_reduce(L.ptr(da), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(smean), L.ptr(sinv), L.ptr(sums), ops.STATS_REPLICAS, Ct.c_int64(P), C, Ct.c_float(0.1), L.stream_ptr())))
     t_a = timeit(lambda: L.check(lib.mgd_bn_act_bwd_apply(L.ptr(da), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(smean), L.ptr(sinv), L.ptr(sums), ops.STATS_REPLICAS, L.ptr(dg), L.ptr(db), L.ptr(dy), Ct.c_int64(P), C, Ct.c_float(0.1), 0, L.stream_ptr())))
     by = 2.0 * P * C
-    print(f"{P:9d} {C:5d} {n:2d} | {t_f:8.1f} {3 * by / t_f / 1e3:6.0f} | {t_r:9.1f} {2 * by / t_r / 1e3:6.0f} | {t_a:9.1f} {3 * by / t_a / 1e3:6.0f}", flush=True)
+    t_c = timeit(lambda: out.copy_(y))                       # the device's own copy at this size: the achievable rate
+    t_ff = timeit(lambda: L.check(lib.mgd_bn_act_fwd_fused(L.ptr(stats), ops.STATS_REPLICAS, Ct.c_float(P), L.ptr(gamma), L.ptr(beta), L.ptr(mm), L.ptr(mv),
+                                                             L.ptr(scale), L.ptr(shift), L.ptr(smean), L.ptr(sinv), Ct.c_float(1e-3), Ct.c_float(0.99), 1,
+                                                             L.ptr(y), None, L.ptr(out), Ct.c_int64(P), C, Ct.c_float(0.1), L.stream_ptr())))
+    print(f"{P:9d} {C:5d} {n:2d} | {t_f:8.1f} {3 * by / t_f / 1e3:6.0f} | {t_r:9.1f} {2 * by / t_r / 1e3:6.0f} | {t_a:9.1f} {3 * by / t_a / 1e3:6.0f} | "
+          f"fused fwd (no residual) {t_ff:7.1f} us {2 * by / t_ff / 1e3:6.0f} GB/s | copy {t_c:7.1f} us {2 * by / t_c / 1e3:6.0f} GB/s", flush=True)
     tot[0] += n * t_f; tot[1] += n * t_r; tot[2] += n * t_a
 print(f"totals per step: fwd {tot[0] / 1e3:.2f} ms (with residual on all), reduce {tot[1] / 1e3:.2f} ms, apply {tot[2] / 1e3:.2f} ms")
