@@ -56,6 +56,12 @@ struct GemmArgs {
   // conv_gemm8_kernel, ncls > 1: ONE launch over several tap classes of one geometry (the four output-parity classes of a
   // stride-2 data gradient): block b works on class b / nblk with that class's packed image, taps and output offset
   int ncls;
+  // K-step order (kernels with wave-uniform K-steps, Ci % 64 == 0): 0 = tap-major (tap, then the 64-channel chunks of the
+  // pixel rows: the packed image's own order), 1 = chunk-major (64-channel chunk, then its taps).  Chunk-major re-reads one
+  // 128-byte segment of every pixel row for all taps before moving on: the re-use distance is a quarter / an eighth of the
+  // tap-major one and stays inside an XCD's 4-MB L2 with 96 blocks in flight (measured: 256 -> 128 at 76 x 76, data gradient,
+  // 338 -> ... MB fetched per launch for 47 MB of operand).
+  int korder;
   const bf16_t* c_wpk[4];
   unsigned long long c_tapcode[4];
   int c_K_pad[4], c_ntaps[4], c_off_h[4], c_off_w[4];

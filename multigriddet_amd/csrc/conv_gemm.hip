@@ -469,8 +469,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   const int wc = wave / WP, wp = wave % WP;
   int bid = (int)blockIdx.x;
   if (a.ncls > 1) {                                   // tap classes in one launch: this block's class (wave-uniform)
-    const int cls = bid / a.nblk;
-    bid -= cls * a.nblk;
+    // class-major: block b works on class b / nblk.  (korder & 2, measurement: the classes of one tile as neighbours on one
+    // XCD, so that they share the source rows in its L2 - 82 us against 62 on the 512-channel layers: blocks with 1 / 2 / 2 / 4
+    // taps side by side leave the CUs unevenly loaded)
+    int cls;
+    if (a.korder & 2) { bid = xcd_remap(bid, a.nblk * a.ncls); cls = bid % a.ncls; bid /= a.ncls; }
+    else { cls = bid / a.nblk; bid = xcd_remap(bid - cls * a.nblk, a.nblk); }
     // (static indices + selects: a runtime index into the by-value argument block sends the whole block to scratch memory -
     // 424 bytes per lane and 15 % of the step, measured)
 #define MGD_PICK(f) (cls == 0 ? a.f[0] : cls == 1 ? a.f[1] : cls == 2 ? a.f[2] : a.f[3])
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     a.out_off_h = MGD_PICK(c_off_h); a.out_off_w = MGD_PICK(c_off_w); a.rowmask = MGD_PICK(c_rowmask); a.colmask = MGD_PICK(c_colmask);
 #undef MGD_PICK
   }
-  const int L = xcd_remap(bid, a.nblk);
+  const int L = a.ncls > 1 ? bid : xcd_remap(bid, a.nblk);
   const int tc = L % a.tilesC, tp = L / a.tilesC;
   const int co0 = tc * BNC, pix0 = tp * BMP;
   if (ABL && (a.dbg & 1024)) return;                  // dispatch cost alone
@@ -535,7 +539,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   }
   const int Kreal = a.ntaps * a.Ci;
   const unsigned lds_w = lds_addr(smem) + wave * 1024;
-  auto issue = [&](int buf) {                          // stages go out in order
+  const int nchunk = a.Ci / BK;                        // chunk-major order (a.korder): 64-channel chunks per tap
+  int s_chunk = 0, s_step = ks_lo;
+  auto issue = [&](int buf) -> int {                   // stages go out in order; returns the K block of the packed image it fetched
     if constexpr (UNI) {
       const unsigned bit = 1u << s_tap;
       const bool kin = s_k0 + kc * 8 < Kreal;             // K padding of the last step reads as zeros
@@ -543,10 +549,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
       for (int i = 0; i < XCH; ++i) vo[i] = ((vmask[i] & bit) && kin) ? xoff[i] + (unsigned)s_toff : 0xFFFFFFF0u;
       dma_rows_asm<XCH, RPR * ROWB>(vo, srd, lds_w + buf * STAGE);
+      if (a.korder & 1) {                                  // (chunk, tap): K_pad == ntaps * Ci, no padding
+        const int wk = s_tap * nchunk + s_chunk;
+        if (++s_tap == a.ntaps) { s_tap = 0; ++s_chunk; }
+        s_toff = tap_off(s_tap) + s_chunk * (BK * 2);
+        return wk;
+      }
+      const int wk = s_k0 / BK;
       s_k0 += BK;
       s_c0 += BK;
       s_toff += BK * 2;
       if (s_c0 >= a.Ci) { s_c0 -= a.Ci; ++s_tap; s_toff = tap_off(s_tap) + s_c0 * 2; }
+      return wk;
     } else {
       unsigned char* xb = smem + buf * STAGE + wave * 1024;
       const int dh = (int)((a.tapcode >> (4 * tap)) & 3) - 1;
@@ -559,6 +573,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       }
       cch += BK;
       while (cch >= a.Ci) { cch -= a.Ci; ++tap; }
+      return s_step++;
     }
   };
 
@@ -590,7 +605,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   };
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (ks_lo + s < nk) { if (!abl_d) issue(s); load_a(af[s], ks_lo + s); }
+    if (ks_lo + s < nk) { int wk = ks_lo + s; if (!abl_d) wk = issue(s); load_a(af[s], wk); }
 
   constexpr int GRP = XCH + 2 * MT;                    // vector-memory instructions per stage: 4 LDS-DMA + 8 fragment loads
   for (int ks0 = ks_lo; ks0 < nk; ks0 += NST) {
@@ -615,8 +630,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       __builtin_amdgcn_sched_barrier(0);
       const int jn = (j + NST - 1) % NST;               // static after unrolling
       if (ks + NST - 1 < nk) {
-        if (!abl_d) issue(jn);
-        if (!abl_a) load_a(af[jn], ks + NST - 1);
+        int wk = ks + NST - 1;
+        if (!abl_d) wk = issue(jn);
+        if (!abl_a) load_a(af[jn], wk);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1620,6 +1636,7 @@ static int conv_args(const mgd_conv_desc* d, GemmArgs& a) {
   MGD_REQUIRE((long long)d->Co_pad * d->K_pad * 2 < (1ll << 32), "conv: packed weights exceed 32-bit byte addressing");
 
   a.ncls = 0;
+  a.korder = 0;
   return MGD_OK;
 }
 
@@ -1763,6 +1780,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   // wave tiles): every weight fragment is loaded by exactly one wave.  form_arg 1: per-lane taps (the round-2 K-step, also
   // taken when a K-step may straddle taps) ----
   MGD_REQUIRE(form == MGD_CONV_AUTO || form == MGD_CONV_GLOBALW, "conv: unknown kernel form %d", form);
+  a.korder = (d->Ci % BK == 0 && d->ntaps > 1 && !(form == MGD_CONV_GLOBALW && d->form_arg == 2)) ? 1 : 0;   // form_arg 2: tap-major
   if (uni && !(form == MGD_CONV_GLOBALW && d->form_arg == 1) && !MGD_DBG(a, 0xFE1)) launch_gemm8<2, 3, 4, true>(a, st);
   else launch_gemm8<2, 3, 4>(a, st);
   MGD_CHECK_LAUNCH("conv_gather_gemm(global weight fragments)");
@@ -1777,7 +1795,7 @@ extern "C" int mgd_conv_gather_gemm_classes(const mgd_conv_desc* d, int n, void*
   GemmArgs a[4];
   for (int c = 0; c < n; ++c) { const int rc = conv_args(d + c, a[c]); if (rc != MGD_OK) return rc; }
   const mgd_conv_desc& r = d[0];
-  MGD_REQUIRE(r.Co_pad % 128 == 0 && r.Ci % 64 == 0 && !r.dst_f32 && !r.latency && r.form == MGD_CONV_AUTO,
+  MGD_REQUIRE(r.Co_pad % 128 == 0 && r.Ci % 64 == 0 && !r.dst_f32 && !r.latency && (r.form == MGD_CONV_AUTO || r.form == MGD_CONV_GLOBALW),
               "conv classes: 128-channel weight tiles, Ci %% 64 == 0, bf16 output, library dispatch");
   for (int c = 1; c < n; ++c) {
     const mgd_conv_desc& q = d[c];
@@ -1785,7 +1803,7 @@ extern "C" int mgd_conv_gather_gemm_classes(const mgd_conv_desc* d, int n, void*
                     q.Hs == r.Hs && q.Ws == r.Ws && q.Ci == r.Ci && q.Hg == r.Hg && q.Wg == r.Wg && q.Hd == r.Hd && q.Wd == r.Wd &&
                     q.Co == r.Co && q.in_stride == r.in_stride && q.out_stride == r.out_stride && q.Co_pad == r.Co_pad &&
                     q.dst_f32 == r.dst_f32 && q.stats_replicas == r.stats_replicas && q.bn_y == r.bn_y && q.bn_sums == r.bn_sums &&
-                    q.act_slope == r.act_slope && !q.latency && q.form == MGD_CONV_AUTO,
+                    q.act_slope == r.act_slope && !q.latency && q.form == r.form,
                 "conv classes: descriptor %d differs from descriptor 0 in more than weights / taps / output offset", c);
   }
   int order[4] = {0, 1, 2, 3};
@@ -1794,6 +1812,8 @@ extern "C" int mgd_conv_gather_gemm_classes(const mgd_conv_desc* d, int n, void*
       if (d[order[j]].K_pad > d[order[i]].K_pad) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
   GemmArgs g = a[order[0]];
   g.ncls = n;
+  // descriptor 0 may force the form (MGD_CONV_GLOBALW) with form_arg bits 2 = tap-major K order, 4 = tile-major blocks (measurement)
+  g.korder = (d[0].form == MGD_CONV_GLOBALW ? ((d[0].form_arg & 2) ? 0 : 1) | ((d[0].form_arg & 4) ? 2 : 0) : 1);
   for (int c = 0; c < n; ++c) {
     const GemmArgs& s = a[order[c]];
     g.c_wpk[c] = s.wpk; g.c_tapcode[c] = s.tapcode; g.c_K_pad[c] = s.K_pad; g.c_ntaps[c] = s.ntaps;

@@ -340,6 +340,9 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
                  for img, kp, cp, _, (ph, pw, tp) in pk.dgrad]
         if S2_CLASSES and descs[0].Co_pad % 128 == 0 and Co % 64 == 0 and not CONV_FORM:
             # the four output-parity classes in ONE launch (mgd_conv_gather_gemm_classes)
+            if S2_CLASSES_ARG:
+                for dd in descs:
+                    dd.form, dd.form_arg = 8, S2_CLASSES_ARG
             arr = (L.ConvDesc * 4)(*descs)
             if PROFILE is None:
                 L.check(lib.mgd_conv_gather_gemm_classes(arr, 4, L.stream_ptr()), "conv_dgrad_s2")
@@ -361,6 +364,7 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
 
 _S2_PATCH = os.environ.get("MGD_S2_PATCH", "1") != "0"
 S2_CLASSES = os.environ.get("MGD_S2_CLASSES", "1") != "0"      # stride-2 data gradient: the four parity classes in one launch
+S2_CLASSES_ARG = int(os.environ.get("MGD_S2_CLASSES_ARG", "0"))   # measurement: 2 = tap-major K order, 4 = tile-major blocks
 _WGRAD_BLOCKS = int(os.environ.get("MGD_WGRAD_BLOCKS", "0"))      # 0: by tile shape
 # kernel form of the weight-gradient launches (mgd_wgrad_desc.form / form_arg; 0 = the library's dispatch): tests and tools
 WGRAD_ROW_FORM = os.environ.get("MGD_WGRAD_ROW", "1") == "1"      # engine: give the kernel-row form its slab workspace (0: never dispatched)

@@ -382,9 +382,10 @@ def test_conv_latency_form_matches_reference(dev, N, H, W, Ci, Co, k, s, cap, ra
 @pytest.mark.parametrize("N,H,W,Ci,Co", [(2, 24, 24, 128, 256), (16, 38, 38, 256, 512), (3, 20, 28, 128, 128)])
 def test_stride2_dgrad_classes_in_one_launch(dev, N, H, W, Ci, Co, monkeypatch):
     """mgd_conv_gather_gemm_classes: the four output-parity classes of a stride-2 data gradient in ONE launch (a block works on
-    class block / tiles) give exactly the tensor of four separate launches - every output pixel belongs to one class and is
-    computed by the same kernel in the same K order - and the same fused BatchNorm-backward sums up to the order of their
-    atomics; both equal the transposed-convolution reference."""
+    class block / tiles) give exactly the tensor of four separate launches of the same kernel form (forced through the
+    descriptor: the library's own choice for a single class may be a form with another K order) - every output pixel belongs to
+    one class and is computed in the same K order - and the same fused BatchNorm-backward sums up to the order of their atomics;
+    both equal the transposed-convolution reference."""
     import torch.nn.functional as F
     from multigriddet_amd import ops
     g = torch.Generator().manual_seed(9 + Ci + Co)
@@ -399,6 +400,7 @@ def test_stride2_dgrad_classes_in_one_launch(dev, N, H, W, Ci, Co, monkeypatch):
     outs, sums = [], []
     for one in (False, True):
         monkeypatch.setattr(ops, "S2_CLASSES", one)
+        monkeypatch.setattr(ops, "CONV_FORM", 0 if one else 8)          # 8 = MGD_CONV_GLOBALW, the form the classes run on
         sm = torch.zeros(ops.STATS_REPLICAS, 2, Ci, device=dev)
         bnred = tuple(t.to(dev) for t in (yprev.to(torch.bfloat16), sc, sh, mu, iv)) + (sm,)
         outs.append(ops.conv_dgrad(dy.to(dev), pk, (H, W), addend=add.to(dev), bnred=bnred))
