@@ -103,7 +103,9 @@ typedef struct mgd_conv_desc {
   int32_t latency;
   /* Kernel form.  0 (MGD_CONV_AUTO): the library chooses from the geometry (measured rules).  Any other
    * value forces one form and fails with MGD_EINVAL when that form cannot run the geometry - for tests and A/B measurements;
-   * the library reads no environment variables.  form_arg: the form's tile selector (0 = its default). */
+   * the library reads no environment variables.  form_arg: low 8 bits = the form's tile selector (0 = its default); with a
+   * forced form + 256 = tap-major K order, + 512 = chunk-major K order (each 64-channel chunk of the pixel rows through all
+   * its taps before the next chunk) where the form's default is the other one. */
   int32_t form;
   int32_t form_arg;
 } mgd_conv_desc;

@@ -790,6 +790,8 @@ __global__ __launch_bounds__(64 * WC) __attribute__((amdgpu_waves_per_eu(2, 2)))
       return (dh * a.Ws + dw) * a.Ci * 2;
     };
     int s_toff = tap_off(0);
+    const int nchunk = a.Ci / BK;
+    int s_chunk = 0;
     // weight fragments of (tile tc, K-step ks): 16 KiB, this wave's four fragments start at wave * 4 KiB
     // (a block of 8 waves spans two consecutive 128-row tiles of the image)
     const char* abase = (const char*)a.wpk + ((size_t)(tc * (WC / 4) + (wave >> 2)) * nk * 16 + (size_t)(wave & 3) * 4) * 1024;
@@ -805,13 +807,20 @@ __global__ __launch_bounds__(64 * WC) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int i = 0; i < XCH; ++i) vo[i] = ((vmask[i] & bit) && kin) ? xoff[i] + (unsigned)s_toff : OOB;
       dma_rows_asm<XCH, RPR * ROWB>(vo, srd, lds0 + buf * STAGE);
-      load_a4_asm(f, lane16, abase + (size_t)min(s_issued, nk - 1) * 16384);
+      // K block of the packed image: the step number (tap-major) or (tap, chunk) of the chunk-major order (GemmArgs::korder)
+      const int wk = (a.korder & 1) ? (real ? s_tap * nchunk + s_chunk : nk - 1) : min(s_issued, nk - 1);
+      load_a4_asm(f, lane16, abase + (size_t)wk * 16384);
       ++s_issued;
       if (real) {
-        s_k0 += BK;
-        s_c0 += BK;
-        s_toff += BK * 2;
-        if (s_c0 >= a.Ci) { s_c0 -= a.Ci; ++s_tap; s_toff = tap_off(s_tap) + s_c0 * 2; }
+        if (a.korder & 1) {
+          if (++s_tap == a.ntaps) { s_tap = 0; ++s_chunk; }
+          s_toff = tap_off(s_tap) + s_chunk * (BK * 2);
+        } else {
+          s_k0 += BK;
+          s_c0 += BK;
+          s_toff += BK * 2;
+          if (s_c0 >= a.Ci) { s_c0 -= a.Ci; ++s_tap; s_toff = tap_off(s_tap) + s_c0 * 2; }
+        }
       }
     };
 
@@ -1648,6 +1657,15 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   const int form = d->form;                       // 0: the rules below; anything else: that form or MGD_EINVAL
   const bool frag = d->Co_pad % 128 == 0;         // the packed image is in fragment order (packed_elem)
   const bool uni = d->ntaps == 1 || d->Ci % 64 == 0;       // (tap, channel) of a K-step is wave-uniform
+  // K order (GemmArgs::korder).  Chunk-major is the default of the 128 x 128 form only: three blocks per CU on the large maps
+  // are what overflows the L2 in tap-major order (256 -> 128 data gradient at 76 x 76: 61 -> 57 us); the counted / ping-pong /
+  // phased forms run the small maps, where it costs 1 - 4 % (a tap_off per K-step) and saves nothing.  A forced form may
+  // ask for the other order: form_arg + 256 = tap-major, + 512 = chunk-major (measurement, tools/bench_forms.py).
+  const int farg = d->form_arg & 255;
+  const bool kmaj_ok = d->Ci % BK == 0 && d->ntaps > 1 && d->K_pad == d->ntaps * d->Ci;
+  const int kmaj_small = (kmaj_ok && form != MGD_CONV_AUTO && (d->form_arg & 512)) ? 1 : 0;
+  const int kmaj_large = (kmaj_ok && !(form != MGD_CONV_AUTO && (d->form_arg & 256))) ? 1 : 0;
+  a.korder = kmaj_small;
   const long long tiles128 = (long long)(d->Co_pad / 128) * cdiv(a.M, 128);
 
   // ---- latency form (a request of its own: mgd_conv_desc.latency) ----
@@ -1705,7 +1723,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   {
     const bool can = !d->dst_f32 && d->Ci % 64 == 0 && d->K_pad == d->ntaps * d->Ci;
     bool want = form == MGD_CONV_PHASED;
-    int shape = d->form_arg;
+    int shape = farg;
     if (form == MGD_CONV_AUTO && can && d->Co_pad % 256 == 0 && d->ntaps > 1 && nk >= 36) {
       const long long t192 = (long long)(d->Co_pad / 256) * cdiv(a.M, 192);
       const long long rounds = (t192 + 255) / 256;
@@ -1737,7 +1755,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
       else if (tiles128 >= 128 && tiles128 <= 512 && nk <= 36) c4 = true;
     }
     if (pp) {
-      const int nt = d->form_arg == 12 ? 12 : 8;
+      const int nt = farg == 12 ? 12 : 8;
 #ifdef MGD_DIAG
       if (nt == 8 && (a.dbg & 4096)) { launch_gemm9<8, 8, 4, true, true>(a, st, 256); MGD_CHECK_LAUNCH("conv_gather_gemm(counted pipeline, ping-pong)"); return MGD_OK; }
 #endif
@@ -1746,7 +1764,7 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
       return MGD_OK;
     }
     if (c4) {
-      const int fa = form == MGD_CONV_COUNTED ? d->form_arg : 0;
+      const int fa = form == MGD_CONV_COUNTED ? farg : 0;
       MGD_REQUIRE(fa == 0 || fa == 12 || fa == 8 || fa == 6 || fa == 4, "conv: counted pipeline: pixel tile / 16 must be 12, 8, 6 or 4");
       const int nt = counted_tile(d, a.M, fa);
       // ring depth: the one (3, 4 or 2) that pads the K-loop least (the loop runs whole groups of NST steps)
@@ -1780,8 +1798,8 @@ extern "C" int mgd_conv_gather_gemm(const mgd_conv_desc* d, void* stream) {
   // wave tiles): every weight fragment is loaded by exactly one wave.  form_arg 1: per-lane taps (the round-2 K-step, also
   // taken when a K-step may straddle taps) ----
   MGD_REQUIRE(form == MGD_CONV_AUTO || form == MGD_CONV_GLOBALW, "conv: unknown kernel form %d", form);
-  a.korder = (d->Ci % BK == 0 && d->ntaps > 1 && !(form == MGD_CONV_GLOBALW && d->form_arg == 2)) ? 1 : 0;   // form_arg 2: tap-major
-  if (uni && !(form == MGD_CONV_GLOBALW && d->form_arg == 1) && !MGD_DBG(a, 0xFE1)) launch_gemm8<2, 3, 4, true>(a, st);
+  a.korder = kmaj_large;
+  if (uni && !(form == MGD_CONV_GLOBALW && farg == 1) && !MGD_DBG(a, 0xFE1)) launch_gemm8<2, 3, 4, true>(a, st);
   else launch_gemm8<2, 3, 4>(a, st);
   MGD_CHECK_LAUNCH("conv_gather_gemm(global weight fragments)");
   return MGD_OK;
@@ -1812,8 +1830,8 @@ extern "C" int mgd_conv_gather_gemm_classes(const mgd_conv_desc* d, int n, void*
       if (d[order[j]].K_pad > d[order[i]].K_pad) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
   GemmArgs g = a[order[0]];
   g.ncls = n;
-  // descriptor 0 may force the form (MGD_CONV_GLOBALW) with form_arg bits 2 = tap-major K order, 4 = tile-major blocks (measurement)
-  g.korder = (d[0].form == MGD_CONV_GLOBALW ? ((d[0].form_arg & 2) ? 0 : 1) | ((d[0].form_arg & 4) ? 2 : 0) : 1);
+  // descriptor 0 may force the form (MGD_CONV_GLOBALW) with form_arg bits 256 = tap-major K order, 4 = tile-major blocks (measurement)
+  g.korder = (d[0].form == MGD_CONV_GLOBALW ? ((d[0].form_arg & 256) ? 0 : 1) | ((d[0].form_arg & 4) ? 2 : 0) : 1);
   for (int c = 0; c < n; ++c) {
     const GemmArgs& s = a[order[c]];
     g.c_wpk[c] = s.wpk; g.c_tapcode[c] = s.tapcode; g.c_K_pad[c] = s.K_pad; g.c_ntaps[c] = s.ntaps;

@@ -140,6 +140,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   // wave-uniform state of the next pixel stage to go out (K-step s_kb): its tap and the byte offset of (tap, first channel)
   int s_kb = 0, s_tap = 0, s_c0 = 0, s_toff = tap_off(0);
+  // chunk-major K order (GemmArgs::korder): the pixel stream and the two weight-half streams each walk (chunk, tap)
+  const int nchunk = Ci / BK, ntaps = a.ntaps;
+  const bool kmaj = (a.korder & 1) != 0;
+  int s_chunk = 0, w_tap0 = 0, w_chunk0 = 0, w_tap1 = 0, w_chunk1 = 0;
 
   // H = 0 / 1: first / second group of the stage's pixel pieces (NB0 / NB1 of them); both go out in order, B1 closes the stage
   auto issue_b = [&](auto H, int st) {
@@ -156,18 +160,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     dma_to<NP>(vo, dd, xsrd);
     if constexpr (h == 1) {
       ++s_kb;
-      s_c0 += BK;
-      s_toff += BK * 2;
-      if (s_c0 >= Ci) { s_c0 = 0; ++s_tap; s_toff = tap_off(s_tap); }
+      if (kmaj) {
+        if (++s_tap == ntaps) { s_tap = 0; ++s_chunk; }
+        s_toff = tap_off(s_tap) + s_chunk * (BK * 2);
+      } else {
+        s_c0 += BK;
+        s_toff += BK * 2;
+        if (s_c0 >= Ci) { s_c0 = 0; ++s_tap; s_toff = tap_off(s_tap); }
+      }
     }
   };
   auto issue_a = [&](auto H, int ks, int st) {
     constexpr int h = decltype(H)::value;
     const bool real = ks < nk && !dg_w;
+    // each half is requested for K-steps 0, 1, 2, ... in order: its own (tap, chunk) walk gives the K block of the image
+    int& wt = h ? w_tap1 : w_tap0;
+    int& wc_ = h ? w_chunk1 : w_chunk0;
+    const int wk = kmaj ? wt * nchunk + wc_ : ks;
+    if (kmaj) { if (++wt == ntaps) { wt = 0; ++wc_; } }
     unsigned vo[NAH], dd[NAH];
 #pragma unroll
     for (int i = 0; i < NAH; ++i) {                           // (everything in the per-lane offset: the range check covers it)
-      vo[i] = real ? a_src[h][i] + (unsigned)ks * 16384u + lane16 : OOB;
+      vo[i] = real ? a_src[h][i] + (unsigned)wk * 16384u + lane16 : OOB;
       dd[i] = ldsb + st * T::STAGE + a_dst[h][i];
     }
     dma_to<NAH>(vo, dd, wsrd);

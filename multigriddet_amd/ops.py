@@ -364,7 +364,7 @@ def conv_dgrad(dy, pk, in_hw, out=None, addend=None, bnred=None):
 
 _S2_PATCH = os.environ.get("MGD_S2_PATCH", "1") != "0"
 S2_CLASSES = os.environ.get("MGD_S2_CLASSES", "1") != "0"      # stride-2 data gradient: the four parity classes in one launch
-S2_CLASSES_ARG = int(os.environ.get("MGD_S2_CLASSES_ARG", "0"))   # measurement: 2 = tap-major K order, 4 = tile-major blocks
+S2_CLASSES_ARG = int(os.environ.get("MGD_S2_CLASSES_ARG", "0"))   # measurement: 256 = tap-major K order, 4 = tile-major blocks
 _WGRAD_BLOCKS = int(os.environ.get("MGD_WGRAD_BLOCKS", "0"))      # 0: by tile shape
 # kernel form of the weight-gradient launches (mgd_wgrad_desc.form / form_arg; 0 = the library's dispatch): tests and tools
 WGRAD_ROW_FORM = os.environ.get("MGD_WGRAD_ROW", "1") == "1"      # engine: give the kernel-row form its slab workspace (0: never dispatched)

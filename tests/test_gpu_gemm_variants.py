@@ -26,6 +26,11 @@ FORMS = [  # name, form, form_arg, expected kernel family
     ("phased 8 waves, 256 x 256", 12, 0, "phased"),
     ("phased 8 waves, 256 x 192", 12, 1, "phased"),
     ("phased 8 waves, 128 x 384", 12, 2, "phased"),
+    # K order: form_arg + 256 = tap-major where chunk-major is the default, + 512 = chunk-major where tap-major is
+    ("global weight fragments, tap-major K order", 8, 256, "global weight fragments"),
+    ("counted pipeline, chunk-major K order", 9, 512, "counted pipeline"),
+    ("ping-pong, 128 pixels, chunk-major K order", 10, 8 + 512, "ping-pong"),
+    ("phased 8 waves, 256 x 192, chunk-major K order", 12, 1 + 512, "phased"),
 ]
 
 
