@@ -50,15 +50,32 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return v;
 }
 
+// Wave-wide reductions on the DPP data path (the result is wave-uniform: lane 63 read back through an SGPR).  Four steps inside
+// the rows of 16 lanes (quad permutes, half-row and row mirrors), then row_bcast:15 / row_bcast:31 carry the row totals into
+// rows 1, 3 and 2, 3.  Seven VALU instructions; the __shfl_xor butterfly these replace is six ds_bpermute round trips through
+// the LDS crossbar per reduction.  Call with every lane of the wave active (as the butterfly needed too).
+template <int CTRL, int ROWMASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                               ROWMASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f32<0xB1>(0.f, v);           // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(0.f, v);           // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(0.f, v);          // row_half_mirror
+  v += dpp_f32<0x140>(0.f, v);          // row_mirror
+  v += dpp_f32<0x142, 0xA>(0.f, v);     // row_bcast:15 into rows 1, 3
+  v += dpp_f32<0x143, 0xC>(0.f, v);     // row_bcast:31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f32<0xB1>(v, v));
+  v = fmaxf(v, dpp_f32<0x4E>(v, v));
+  v = fmaxf(v, dpp_f32<0x141>(v, v));
+  v = fmaxf(v, dpp_f32<0x140>(v, v));
+  v = fmaxf(v, dpp_f32<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_f32<0x143, 0xC>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of logical

@@ -389,6 +389,217 @@ __global__ __launch_bounds__(256) void loss_cell_kernel(LossArgs a, CellsPerBloc
   }
 }
 
+// ---- K2' (round 4): the same per-cell loss for the configurations WITHOUT an IoU localisation loss or softmax focal
+// classification (every default), laid out for the vector ALU.  loss_cell_kernel spends one wave per cell - 1 090 wave
+// instructions for 88 channels, 8 of them the cell's own scalars computed on all 64 lanes, and the kernel is bound by the
+// vector ALU (PMC: 1.3e8 VALU instructions per launch = the whole 228 us).  Here a block of 256 threads owns 64 cells:
+//   A1  thread (q, cell) = (tid / 64, tid % 64): IoU of the cell's predicted box under every anchor against the ground-truth
+//       boxes g = q, q + 4, ... of the image (list in LDS, broadcast reads) -> partial maxima in LDS;
+//   A2  thread = cell (64 threads): ignore mask, objectness target / weight, the losses and gradients of the 5 + A header
+//       channels; the cell's `obj` goes to LDS;
+//   B   thread = (cell, class) elements, 256 at a time: the class channels, element-wise.
+// Same arithmetic per channel as loss_cell_kernel (the sums are added in another order).
+constexpr int C2_CELLS = 64;
+__global__ __launch_bounds__(256) void loss_cell2_kernel(LossArgs a) {
+  const mgd_loss_cfg& c = a.cfg;
+  const int l = blockIdx.z;
+  const int gh = c.grid_h[l], gw = c.grid_w[l], A = c.A, C = c.C, F = 5 + A + C;
+  const int cell_beg = blockIdx.x * C2_CELLS;
+  if (cell_beg >= gh * gw) return;                    // block-uniform: this scale has fewer chunks than the widest one
+  const int ncell = min(C2_CELLS, gh * gw - cell_beg);
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float4 gts[GT_LDS];
+  __shared__ float part[4][MAXA][C2_CELLS];
+  __shared__ float cell_obj[C2_CELLS];
+  __shared__ float wsum[4][4];
+
+  const int ngt = a.gt_count[l * c.B + b];
+  const float4* gtg = a.gt + a.cell_off[l] + (long long)b * gh * gw;
+  const bool in_lds = ngt <= GT_LDS;
+  if (in_lds)
+    for (int i = tid; i < ngt; i += 256) gts[i] = gtg[i];
+
+  const float nf = norm_factor(c, l, a.npos[l]);
+  const float inv_nf = 1.0f / nf;
+  const float sx = (float)c.in_w / (float)gw, sy = (float)c.in_h / (float)gh;
+  const float gscale = c.grad_out_scale;
+  const long long cell0 = (long long)b * gh * gw + cell_beg;     // first cell of the block in the scale's tensors
+  const float* P = a.yp[l] + cell0 * F;
+  const float* T = a.yt[l] + cell0 * F;
+
+  // ---- A1: partial IoU maxima
+  const int ci = lane;                                 // cell of this thread in phases A1 / A2
+  const bool cell_ok = ci < ncell;
+  float pxr = 0.f, pyr = 0.f, pwr = 0.f, phr = 0.f;
+  if (cell_ok) {
+    const float* p = P + (long long)ci * F;
+    pxr = p[0]; pyr = p[1]; pwr = p[2]; phr = p[3];
+  }
+  const int row = (cell_beg + ci) / gw, col = (cell_beg + ci) - row * gw;
+  const float ax = xy_act(pxr), ay = xy_act(pyr);
+  const float bx = (ax + (float)row) * sx, by = (ay + (float)col) * sy;   // transposed grid as in the reference
+  const float ew = __expf(pwr), eh = __expf(phr);
+  float iou_a[MAXA];
+#pragma unroll
+  for (int j = 0; j < MAXA; ++j) iou_a[j] = 0.f;
+  __syncthreads();                                     // gts staged
+  for (int g = wave; g < ngt; g += 4) {
+    const float4 G = in_lds ? gts[g] : gtg[g];
+    const float gx0 = G.x - G.z / 2.0f, gx1 = G.x + G.z / 2.0f, gy0 = G.y - G.w / 2.0f, gy1 = G.y + G.w / 2.0f;
+    const float garea = G.z * G.w;
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j) {
+      if (j < A) {
+        const float w = ew * c.anchors[l][j][0] * sx, h = eh * c.anchors[l][j][1] * sy;
+        const float iw = fmaxf(fminf(bx + w / 2.0f, gx1) - fmaxf(bx - w / 2.0f, gx0), 0.f);
+        const float ih = fmaxf(fminf(by + h / 2.0f, gy1) - fmaxf(by - h / 2.0f, gy0), 0.f);
+        const float inter = iw * ih;
+        const float iou = inter / (w * h + garea - inter + KEPS);
+        iou_a[j] = fmaxf(iou_a[j], iou);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXA; ++j)
+    if (j < A) part[wave][j][ci] = iou_a[j];
+  __syncthreads();
+
+  // ---- A2: the cell's scalars and its 5 + A header channels (wave 0)
+  float s_loc = 0.f, s_obj = 0.f, s_anc = 0.f, s_cls = 0.f;
+  if (wave == 0) {
+    float obj = 0.f;
+    if (cell_ok) {
+      const float* p = P + (long long)ci * F;
+      const float* t = T + (long long)ci * F;
+      float max_iou = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXA; ++j)
+        if (j < A) {
+          iou_a[j] = fmaxf(fmaxf(part[0][j][ci], part[1][j][ci]), fmaxf(part[2][j][ci], part[3][j][ci]));
+          max_iou = j == 0 ? iou_a[0] : fmaxf(max_iou, iou_a[j]);
+        }
+      const float t_x = t[0], t_y = t[1], t_w = t[2], t_h = t[3], tob = t[4];
+      obj = tob > 0.5f ? 1.f : 0.f;
+      const float ignore = (max_iou > c.ignore_thresh && tob < 0.5f) ? 1.f : 0.f;
+      float tanc[MAXA], panc[MAXA];
+#pragma unroll
+      for (int j = 0; j < MAXA; ++j) {
+        tanc[j] = j < A ? t[5 + j] : 0.f;
+        panc[j] = j < A ? p[5 + j] : 0.f;
+      }
+      int kstar = 0;
+      {
+        float best = tanc[0];
+#pragma unroll
+        for (int j = 1; j < MAXA; ++j)
+          if (j < A && tanc[j] > best) { best = tanc[j]; kstar = j; }
+      }
+      float assigned = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXA; ++j)
+        if (j == kstar) assigned = iou_a[j];
+      assigned *= obj;
+      a.assigned[a.cell_off[l] + cell0 + ci] = assigned;
+      float tgt = tob;
+      if (c.use_iou_aware_objectness) {
+        const float piou = fminf(fmaxf(assigned, 0.f), 1.f);
+        const float blended = c.iou_objectness_ratio * powf(piou + KEPS, c.iou_objectness_power) +
+                              (1.f - c.iou_objectness_ratio) * tob;
+        tgt = obj * blended + (1.f - obj) * tgt;
+      }
+      float wobj = obj * c.object_scale + (1.f - obj) * (1.f - ignore) * c.no_object_scale;
+      if (c.trainable_nms_weight > 0.f)
+        wobj += (1.f - obj) * ignore * c.trainable_nms_weight *
+                powf(fminf(fmaxf(max_iou, 0.f), 1.f) + KEPS, c.trainable_nms_power);
+      float g[5 + MAXA];
+      {                                                 // x, y: squared error on the activated offsets
+        const float dx = ax - t_x, dy = ay - t_y;
+        s_loc += obj * dx * dx;
+        s_loc += obj * dy * dy;
+        g[0] = c.coord_scale * obj * 2.f * dx * xy_act_grad(pxr) * inv_nf;
+        g[1] = c.coord_scale * obj * 2.f * dy * xy_act_grad(pyr) * inv_nf;
+        const float dw = pwr - t_w, dh = phr - t_h;     // w, h: squared error on the raw log-ratios
+        s_loc += obj * dw * dw;
+        s_loc += obj * dh * dh;
+        g[2] = c.coord_scale * obj * 2.f * dw * inv_nf;
+        g[3] = c.coord_scale * obj * 2.f * dh * inv_nf;
+      }
+      {
+        const float pob = p[4];
+        s_obj += bce_logits(tgt, pob) * wobj;
+        g[4] = c.object_scale * wobj * (sigmoidf(pob) - tgt) * inv_nf;
+      }
+      const float m = obj * (1.f - ignore);
+#pragma unroll
+      for (int j = 0; j < MAXA; ++j)
+        if (j < A) {
+          s_anc += bce_logits(tanc[j], panc[j]) * m;
+          g[5 + j] = c.anchor_scale * c.anchor_scale * m * (sigmoidf(panc[j]) - tanc[j]) * inv_nf;
+        }
+      float* gf = a.gf[l] ? a.gf[l] + (cell0 + ci) * F : nullptr;
+      bf16_t* gb = a.gb[l] ? a.gb[l] + (cell0 + ci) * F : nullptr;
+#pragma unroll
+      for (int j = 0; j < 5 + MAXA; ++j)
+        if (j < 5 + A) {
+          const float v = g[j] * gscale;
+          if (gf) gf[j] = v;
+          if (gb) gb[j] = f2bf(v);
+        }
+    }
+    cell_obj[ci] = obj;
+  }
+  __syncthreads();
+
+  // ---- B: class channels, element (cell, class) = e / C, e % C
+  {
+    const int nel = ncell * C;
+    const int dq = 256 / C, dr = 256 - dq * C;
+    int cell = tid / C, k = tid - cell * C;
+    const float* Pc = P + 5 + A;
+    const float* Tc = T + 5 + A;
+    float* gfc = a.gf[l] ? a.gf[l] + cell0 * F + 5 + A : nullptr;
+    bf16_t* gbc = a.gb[l] ? a.gb[l] + cell0 * F + 5 + A : nullptr;
+    for (int e = tid; e < nel; e += 256) {
+      const long long off = (long long)cell * F + k;
+      const float pv = Pc[off], tv = Tc[off];
+      const float obj = cell_obj[cell];
+      const float cw = a.class_w ? a.class_w[k] : 1.f;
+      float gout;
+      if (c.use_focal_loss) {
+        const float pr = sigmoidf(pv);
+        const float pt = tv * pr + (1.f - tv) * (1.f - pr);
+        const float om = fmaxf(1.f - pt, 0.f);
+        const float mod = powf(om, c.focal_gamma);
+        const float at = tv * c.focal_alpha + (1.f - tv) * (1.f - c.focal_alpha);
+        const float bce = bce_logits(tv, pv);
+        s_cls += mod * at * bce * cw * obj;
+        const float dmod = om > 0.f ? -c.focal_gamma * powf(om, c.focal_gamma - 1.f) * (2.f * tv - 1.f) * pr * (1.f - pr) : 0.f;
+        gout = c.class_scale * cw * obj * at * (dmod * bce + mod * (pr - tv)) * inv_nf;
+      } else {
+        const float ts = c.label_smoothing > 0.f ? tv * (1.f - c.label_smoothing) + c.label_smoothing / (float)C : tv;
+        s_cls += bce_logits(ts, pv) * cw * obj;
+        gout = c.class_scale * cw * obj * (sigmoidf(pv) - ts) * inv_nf;
+      }
+      gout *= gscale;
+      if (gfc) gfc[off] = gout;
+      if (gbc) gbc[off] = f2bf(gout);
+      cell += dq;
+      k += dr;
+      if (k >= C) { k -= C; ++cell; }
+    }
+  }
+  s_loc = wave_sum(s_loc); s_obj = wave_sum(s_obj); s_anc = wave_sum(s_anc); s_cls = wave_sum(s_cls);
+  if (lane == 0) { wsum[wave][0] = s_loc; wsum[wave][1] = s_obj; wsum[wave][2] = s_anc; wsum[wave][3] = s_cls; }
+  __syncthreads();
+  if (tid < 4) {
+    float v = wsum[0][tid] + wsum[1][tid] + wsum[2][tid] + wsum[3][tid];
+    v *= inv_nf;
+    if (tid == 2) v *= c.anchor_scale;                 // reference accumulates anchor_scale * anchor_loss (:349,:390)
+    atomicAdd(a.acc + tid, (double)v);
+  }
+}
+
 // ---- K3: variance consensus (reference :930-1043), kernel size 3.  One wave per centre cell.
 __global__ __launch_bounds__(256) void loss_consensus_kernel(LossArgs a, int l) {
   const mgd_loss_cfg& c = a.cfg;
@@ -612,7 +823,13 @@ extern "C" int mgd_loss_fwd_bwd(const mgd_loss_cfg* cfg, const float* const* y_p
     cpbs.v[l] = cpb;
     max_gx = std::max(max_gx, (int)cdiv(cells, cpb));
   }
-  hipLaunchKernelGGL(loss_cell_kernel, dim3(max_gx, cfg->B, cfg->L), dim3(256), 0, st, al, cpbs);
+  if (cfg->iou_loss == 0 && !cfg->use_softmax_focal) {
+    long long max_cells = 0;
+    for (int l = 0; l < cfg->L; ++l) max_cells = std::max(max_cells, (long long)cfg->grid_h[l] * cfg->grid_w[l]);
+    hipLaunchKernelGGL(loss_cell2_kernel, dim3(cdiv(max_cells, C2_CELLS), cfg->B, cfg->L), dim3(256), 0, st, al);
+  } else {
+    hipLaunchKernelGGL(loss_cell_kernel, dim3(max_gx, cfg->B, cfg->L), dim3(256), 0, st, al, cpbs);
+  }
   if (cfg->use_consensus_loss) {
     for (int l = 0; l < cfg->L; ++l) {
       if (!a.gf[l]) continue;
