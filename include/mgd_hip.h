@@ -356,7 +356,8 @@ int mgd_loss_fwd_bwd(const mgd_loss_cfg* cfg, const float* const* y_pred_host, c
  * 262-283) and greedy / soft NMS + top-k + xyxy (postprocess/nms.py:83-385,
  * multigrid_decode.py:300-345, 397-422).  Batched over images.
  * cand layout per image: boxes f32 [cap][4] (top-left xywh, image px), score f32 [cap], cls i32 [cap],
- * count i32.  Candidates are emitted in the reference's row order (scale-major, then cell).
+ * count i32.  Candidates are emitted in the reference's row order (scale-major, then cell).  The output buffers may be
+ * uninitialised: the kernels write every count and zero every slot past it (candidates and detections alike).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct mgd_decode_cfg {
   int32_t L, A, C, B;

@@ -143,6 +143,13 @@ __global__ __launch_bounds__(1024) void compact_kernel(DecArgs a) {
     __syncthreads();
   }
   if (threadIdx.x == 0) a.ocount[b] = min(base, c.cap);
+  // candidates past the count read as zeros (the caller hands over uninitialised buffers)
+  for (int pos = min(base, c.cap) + (int)threadIdx.x; pos < c.cap; pos += 1024) {
+    const long long dst = (long long)b * c.cap + pos;
+    *(float4*)(a.oboxes + dst * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    a.oscores[dst] = 0.f;
+    a.ocls[dst] = 0;
+  }
 }
 
 struct NmsArgs {
@@ -159,6 +166,16 @@ struct NmsArgs {
   int* out_count;
   float* sorted;        // ws [B][cap][4]
 };
+
+// Output slots past the image's detection count read as zeros (out_boxes is 16 bytes per slot in either format).
+__device__ __forceinline__ void zero_tail(const NmsArgs& a, int b, int K, int tid) {
+  for (int k = K + tid; k < a.max_boxes; k += 1024) {
+    const long long o = (long long)b * a.max_boxes + k;
+    *(float4*)((float*)a.out_boxes + o * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    a.out_scores[o] = 0.f;
+    a.out_cls[o] = 0;
+  }
+}
 
 __device__ __forceinline__ float pair_metric(const float4 A, const float4 Bx, int method) {
   float x1 = A.x, y1 = A.y, w1 = A.z, h1 = A.w, x2 = Bx.x, y2 = Bx.y, w2 = Bx.z, h2 = Bx.w;
@@ -253,6 +270,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(NmsArgs a) {
     __syncthreads();
   }
   if (tid == 0) a.out_count[b] = K;
+  zero_tail(a, b, K, tid);
   __syncthreads();
   float ih = a.image_hw[b * 2], iw = a.image_hw[b * 2 + 1];
   for (int k = tid; k < K; k += 1024) {
@@ -357,6 +375,7 @@ __global__ __launch_bounds__(1024) void soft_nms_kernel(NmsArgs a) {
   bitonic_desc(keys, np2, tid);
   const int Ko = min(K, a.max_boxes);
   if (tid == 0) a.out_count[b] = Ko;
+  zero_tail(a, b, Ko, tid);
   const float ih = a.image_hw[b * 2], iw = a.image_hw[b * 2 + 1];
   for (int k = tid; k < Ko; k += 1024) {
     int i = (int)(keys[k] & 0xffffffffu) - 1;
@@ -488,6 +507,7 @@ __global__ __launch_bounds__(1024) void wbf_kernel(NmsArgs a) {
   const float ih = a.image_hw[b * 2], iw = a.image_hw[b * 2 + 1];
   const int Ko = min(K, a.max_boxes);
   if (tid == 0) a.out_count[b] = Ko;
+  zero_tail(a, b, Ko, tid);
   if (K > a.max_boxes) {
     int kp2 = 1;
     while (kp2 < K) kp2 <<= 1;

@@ -690,10 +690,11 @@ def decode(cfg, y_pred, image_hw):
     need = lib.mgd_decode_workspace_size(C.byref(cfg))
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     B, cap = cfg.B, cfg.cap
-    boxes = torch.zeros(B, cap, 4, dtype=torch.float32, device=dev)
-    scores = torch.zeros(B, cap, dtype=torch.float32, device=dev)
-    cls = torch.zeros(B, cap, dtype=torch.int32, device=dev)
-    count = torch.zeros(B, dtype=torch.int32, device=dev)
+    # (uninitialised: the kernels write the count and zero every slot past it)
+    boxes = torch.empty(B, cap, 4, dtype=torch.float32, device=dev)
+    scores = torch.empty(B, cap, dtype=torch.float32, device=dev)
+    cls = torch.empty(B, cap, dtype=torch.int32, device=dev)
+    count = torch.empty(B, dtype=torch.int32, device=dev)
     yp = (C.c_void_p * cfg.L)(*[t.data_ptr() for t in y_pred])
     L.check(lib.mgd_decode(C.byref(cfg), yp, L.ptr(image_hw), L.ptr(boxes), L.ptr(scores), L.ptr(cls), L.ptr(count),
                            L.ptr(ws), C.c_size_t(need), L.stream_ptr()), "decode")
@@ -716,10 +717,10 @@ def nms(boxes, scores, cls, count, image_hw, method="diou", threshold=0.5, max_b
     wbf = method == "wbf"
     need = lib.mgd_wbf_workspace_size(B, cap) if wbf else lib.mgd_nms_workspace_size(B, cap)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
-    ob = torch.zeros(B, max_boxes, 4, dtype=torch.int32 if return_xyxy else torch.float32, device=dev)
-    osc = torch.zeros(B, max_boxes, dtype=torch.float32, device=dev)
-    ocl = torch.zeros(B, max_boxes, dtype=torch.int32, device=dev)
-    ocn = torch.zeros(B, dtype=torch.int32, device=dev)
+    ob = torch.empty(B, max_boxes, 4, dtype=torch.int32 if return_xyxy else torch.float32, device=dev)
+    osc = torch.empty(B, max_boxes, dtype=torch.float32, device=dev)
+    ocl = torch.empty(B, max_boxes, dtype=torch.int32, device=dev)
+    ocn = torch.empty(B, dtype=torch.int32, device=dev)
     if wbf:
         L.check(lib.mgd_wbf(L.ptr(boxes), L.ptr(scores), L.ptr(cls), L.ptr(count), B, cap, C.c_float(threshold),
                             max_boxes, L.ptr(image_hw), int(return_xyxy), L.ptr(ob), L.ptr(osc), L.ptr(ocl), L.ptr(ocn),
