@@ -45,7 +45,7 @@ class MultiGridDecoder:
         outs = [self._dev(o) for o in outputs]
         B = outs[0].shape[0]
         grids = [(int(o.shape[1]), int(o.shape[2])) for o in outs]
-        ihw = torch.as_tensor(np.asarray(image_shapes, np.float32).reshape(B, 2)).cuda()
+        ihw = self._image_hw(image_shapes, B)
         cfg = ops.make_decode_cfg(self.anchors, self.num_classes, self.input_shape, B, grids, confidence,
                                   use_softmax=self.use_softmax, rescore=self.rescore_confidence,
                                   tag_scale=per_scale_nms)
@@ -54,6 +54,19 @@ class MultiGridDecoder:
         b, s, c, n = ops.decode(cfg, outs, ihw)
         return ops.nms(b, s, c, n, ihw, method="wbf" if use_wbf else nms_method, threshold=nms_threshold,
                        max_boxes=max_boxes, return_xyxy=return_xyxy, per_scale=per_scale_nms)
+
+    def _image_hw(self, image_shapes, B):
+        """[B,2] fp32 device tensor of the original image sizes; the upload of a shape set seen before is re-used (a stream of
+        frames from one camera pays the host-to-device copy once)."""
+        arr = np.asarray(image_shapes, np.float32).reshape(B, 2)
+        key = arr.tobytes()
+        cache = self.__dict__.setdefault("_ihw_cache", {})
+        t = cache.get(key)
+        if t is None:
+            if len(cache) >= 64:
+                cache.clear()
+            t = cache[key] = torch.as_tensor(arr).cuda()
+        return t
 
     def postprocess(self, multigriddet_outputs, image_shape, model_image_size, max_boxes: int = 100,
                     confidence: float = 0.1, nms_threshold: float = 0.5, use_iol: bool = True,
