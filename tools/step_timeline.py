@@ -52,7 +52,7 @@ def main():
             cur_e = max(cur_e, e)
     cover += cur_e - cur_s
     print(f"no kernel on any queue: {(t1 - t0 - cover) / 1e6:.3f} ms")
-    loss = [r for r in step if "loss_cell_kernel" in r[2]]
+    loss = [r for r in step if "loss_cell" in r[2]]
     wg = [r for r in step if "wgrad" in r[2]]
     t_loss = loss[0][0] if loss else t0
     t_bwd = max(r[1] for r in wg) if wg else t1
