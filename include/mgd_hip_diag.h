@@ -30,6 +30,12 @@ int mgd_debug_wgrad_skeleton(float* out, int blocks, int iters, int mode, void* 
 /* The same for the gather-GEMM's K-step (ds_read_b128 fragments, weights as register loads or from LDS), by tile shape. */
 int mgd_debug_gemm_skeleton(float* out, int blocks, int iters, int shape, void* stream);
 
+/* Vector-memory issue rate of a CU: `blocks` workgroups of `waves` (1, 2, 4, 8) waves each issue iters x 8 vector-memory
+ * instructions of one kind and nothing else.  kind 0 = buffer_load_dwordx4 ... lds over an L2-resident `window` of buf, 1 = the
+ * same with every lane out of range, 2 = buffer_load_dwordx4 into registers, 3 = buffer_load_dword ... lds, 4 = buffer_load_dword
+ * into a register, 5 = global_load_dwordx4, 6 = kind 2 with every lane out of range (tools/vmem_rate.py). */
+int mgd_debug_vmem_rate(const void* buf, unsigned window, float* out, int blocks, int waves, int iters, int kind, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,7 +121,7 @@ EXPORTS = [
 
 # what libmgd_hip_diag.so exports on top (include/mgd_hip_diag.h)
 DIAG_EXPORTS = ["mgd_diag_set_flags", "mgd_diag_flags_value", "mgd_debug_stamps", "mgd_debug_mfma_peak",
-                "mgd_debug_wgrad_skeleton", "mgd_debug_gemm_skeleton"]
+                "mgd_debug_wgrad_skeleton", "mgd_debug_gemm_skeleton", "mgd_debug_vmem_rate"]
 
 
 # ---------------------------------------------------------------------------------------------- launch plans (csrc/plan.cpp)

@@ -352,6 +352,111 @@ extern "C" int mgd_debug_mfma_peak(float* out, int blocks, int iters, int nacc, 
   return MGD_OK;
 }
 
+// ---- vector-memory issue rate of a CU (tools/vmem_rate.py): NW waves of ONE workgroup per CU each issue iters x 8 vector-memory
+// instructions of one kind and nothing else (a vmcnt(0) per group of 8).  kind: 0 = buffer_load_dwordx4 ... lds (LDS-DMA, 1 KiB
+// per wave-instruction) over an L2-resident window, 1 = the same with every lane out of range (no memory traffic at all),
+// 2 = buffer_load_dwordx4 into registers, 3 = buffer_load_dword ... lds (256 B per wave-instruction), 4 = buffer_load_dword
+// into a register, 5 = global_load_dwordx4 (flat addressing) into registers, 6 = buffer_load_dwordx4 into registers, every lane
+// out of range.
+namespace {
+template <int NW, int KIND>
+__global__ __launch_bounds__(64 * NW) void vmem_rate_kernel(const unsigned char* buf, float* out, int iters, unsigned window) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  i32x4 srd;
+  {
+    const unsigned long long p = (unsigned long long)buf;
+    srd[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+    srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    srd[2] = __builtin_amdgcn_readfirstlane((int)window);
+    srd[3] = 0x00020000;
+  }
+  constexpr bool oob = KIND == 1 || KIND == 6;
+  constexpr int W = (KIND == 3 || KIND == 4) ? 4 : 16;              // bytes per lane
+  unsigned vo = oob ? 0xFFFFFFF0u : (unsigned)((blockIdx.x * NW + wave) * 8192 % (window - 8192) + lane * W);
+  const unsigned lds = lds_addr(smem) + wave * 8192;
+  f32x4 r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_nop 4" ::: "memory");                                // H1: the descriptor words came from v_readfirstlane
+  if constexpr (KIND == 0 || KIND == 1 || KIND == 3) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds) : "memory");
+  }
+  for (int it = 0; it < iters; ++it) {
+    if constexpr (KIND == 0 || KIND == 1) {
+      asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds\n\tbuffer_load_dwordx4 %0, %1, 0 offen offset:1024 lds\n\t"
+                   "buffer_load_dwordx4 %0, %1, 0 offen offset:2048 lds\n\tbuffer_load_dwordx4 %0, %1, 0 offen offset:3072 lds\n\t"
+                   "buffer_load_dwordx4 %0, %1, 0 offen lds\n\tbuffer_load_dwordx4 %0, %1, 0 offen offset:1024 lds\n\t"
+                   "buffer_load_dwordx4 %0, %1, 0 offen offset:2048 lds\n\tbuffer_load_dwordx4 %0, %1, 0 offen offset:3072 lds\n\t"
+                   "s_waitcnt vmcnt(0)" ::"v"(vo), "s"(srd) : "memory");
+    } else if constexpr (KIND == 3) {
+      asm volatile("buffer_load_dword %0, %1, 0 offen lds\n\tbuffer_load_dword %0, %1, 0 offen offset:256 lds\n\t"
+                   "buffer_load_dword %0, %1, 0 offen offset:512 lds\n\tbuffer_load_dword %0, %1, 0 offen offset:768 lds\n\t"
+                   "buffer_load_dword %0, %1, 0 offen lds\n\tbuffer_load_dword %0, %1, 0 offen offset:256 lds\n\t"
+                   "buffer_load_dword %0, %1, 0 offen offset:512 lds\n\tbuffer_load_dword %0, %1, 0 offen offset:768 lds\n\t"
+                   "s_waitcnt vmcnt(0)" ::"v"(vo), "s"(srd) : "memory");
+    } else if constexpr (KIND == 2 || KIND == 6) {
+      asm volatile("buffer_load_dwordx4 %0, %8, %9, 0 offen\n\tbuffer_load_dwordx4 %1, %8, %9, 0 offen offset:1024\n\t"
+                   "buffer_load_dwordx4 %2, %8, %9, 0 offen offset:2048\n\tbuffer_load_dwordx4 %3, %8, %9, 0 offen offset:3072\n\t"
+                   "buffer_load_dwordx4 %4, %8, %9, 0 offen\n\tbuffer_load_dwordx4 %5, %8, %9, 0 offen offset:1024\n\t"
+                   "buffer_load_dwordx4 %6, %8, %9, 0 offen offset:2048\n\tbuffer_load_dwordx4 %7, %8, %9, 0 offen offset:3072\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                   : "v"(vo), "s"(srd) : "memory");
+    } else if constexpr (KIND == 4) {
+      float t[8];
+      asm volatile("buffer_load_dword %0, %8, %9, 0 offen\n\tbuffer_load_dword %1, %8, %9, 0 offen offset:256\n\t"
+                   "buffer_load_dword %2, %8, %9, 0 offen offset:512\n\tbuffer_load_dword %3, %8, %9, 0 offen offset:768\n\t"
+                   "buffer_load_dword %4, %8, %9, 0 offen\n\tbuffer_load_dword %5, %8, %9, 0 offen offset:256\n\t"
+                   "buffer_load_dword %6, %8, %9, 0 offen offset:512\n\tbuffer_load_dword %7, %8, %9, 0 offen offset:768\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                   : "v"(vo), "s"(srd) : "memory");
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j][0] += t[j];
+    } else {
+      asm volatile("global_load_dwordx4 %0, %8, %9 offset:0\n\tglobal_load_dwordx4 %1, %8, %9 offset:1024\n\t"
+                   "global_load_dwordx4 %2, %8, %9 offset:2048\n\tglobal_load_dwordx4 %3, %8, %9 offset:3072\n\t"
+                   "global_load_dwordx4 %4, %8, %9 offset:0\n\tglobal_load_dwordx4 %5, %8, %9 offset:1024\n\t"
+                   "global_load_dwordx4 %6, %8, %9 offset:2048\n\tglobal_load_dwordx4 %7, %8, %9 offset:3072\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                   : "v"(vo), "s"(buf) : "memory");
+    }
+  }
+  f32x4 t = r[0];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) t += r[j];
+  if (t[0] == 123.456f) out[threadIdx.x] = t[1] + smem[lane];          // keep everything alive
+}
+
+template <int NW>
+void launch_vmem_rate(const unsigned char* buf, float* out, int blocks, int iters, int kind, unsigned window, hipStream_t st) {
+#define MGD_VR(K) hipLaunchKernelGGL((vmem_rate_kernel<NW, K>), dim3(blocks), dim3(64 * NW), NW * 8192, st, buf, out, iters, window)
+  switch (kind) {
+    case 0: MGD_VR(0); break; case 1: MGD_VR(1); break; case 2: MGD_VR(2); break; case 3: MGD_VR(3); break;
+    case 4: MGD_VR(4); break; case 5: MGD_VR(5); break; default: MGD_VR(6); break;
+  }
+#undef MGD_VR
+}
+}  // namespace
+
+extern "C" int mgd_debug_vmem_rate(const void* buf, unsigned window, float* out, int blocks, int waves, int iters, int kind,
+                                   void* stream) {
+  MGD_REQUIRE(buf && out && blocks >= 1 && iters >= 1 && kind >= 0 && kind <= 6 && window >= (1u << 20),
+              "vmem_rate: arguments (window >= 1 MiB)");
+  hipStream_t st = (hipStream_t)stream;
+  switch (waves) {
+    case 1: launch_vmem_rate<1>((const unsigned char*)buf, out, blocks, iters, kind, window, st); break;
+    case 2: launch_vmem_rate<2>((const unsigned char*)buf, out, blocks, iters, kind, window, st); break;
+    case 4: launch_vmem_rate<4>((const unsigned char*)buf, out, blocks, iters, kind, window, st); break;
+    case 8: launch_vmem_rate<8>((const unsigned char*)buf, out, blocks, iters, kind, window, st); break;
+    default: MGD_REQUIRE(false, "vmem_rate: waves must be 1, 2, 4 or 8");
+  }
+  MGD_CHECK_LAUNCH("vmem_rate");
+  return MGD_OK;
+}
+
 static int g_diag_flags = 0;
 extern "C" int mgd_diag_set_flags(int flags) {
   g_diag_flags = flags;
