@@ -19,12 +19,13 @@ y = torch.empty(B, ho, ho, co, dtype=torch.bfloat16, device=dev)
 dx = torch.empty(B, h, h, ci, dtype=torch.bfloat16, device=dev)
 dw = torch.zeros(co, k * k, ci, device=dev)
 stats = torch.zeros(ops.STATS_REPLICAS, 2, co, device=dev)
+ws = torch.empty(16 << 20, dtype=torch.float32, device=dev)          # slab workspace of the kernel-row weight gradient
 for _ in range(iters):
     if mode == "fwd":
         ops.conv_fwd(x, pk, out=y, stats=stats)
     elif mode == "dgrad":
         ops.conv_dgrad(dy, pk, (h, h), out=dx)
     else:
-        ops.conv_wgrad(x, dy, dw, k, s)
+        ops.conv_wgrad(x, dy, dw, k, s, ws=ws, row_blocks=0)
 torch.cuda.synchronize()
 print("done", mode, ci, co, k, s, h, B)
