@@ -206,3 +206,37 @@ def test_config5_mosaic_mixup_gridmask_at_608_batch16():
     torch.cuda.synchronize()
     np.testing.assert_allclose(mi.cpu().numpy(), rmi, rtol=1e-6, atol=1e-4)
     assert np.array_equal(mb.cpu().numpy(), rmb)
+
+
+@pytest.mark.parametrize("ci,co,k,h", [(128, 256, 3, 76), (256, 512, 3, 38), (512, 1024, 3, 19), (64, 128, 3, 152), (256, 128, 1, 76)])
+def test_config2_weight_gradient_forms_on_random_data(ci, co, k, h):
+    """Every weight-gradient kernel form at the benchmark shapes (batch 16) on random bf16 operands against an fp32 reference
+    computed tap by tap on the device (einsum over the zero-padded input - the checker, not the product): the per-tap and
+    descriptor-addressed forms, the kernel-row form with atomics and with its slab workspace, and the library's own choice.
+    fp32 accumulation of the same bf16 products: they agree to accumulation order (2e-5 of the largest entry)."""
+    from multigriddet_amd import ops
+    dev = torch.device("cuda:0")
+    torch.backends.cuda.matmul.allow_tf32 = False
+    g = torch.Generator(device=dev).manual_seed(ci + co + h)
+    x = torch.randn(B, h, h, ci, device=dev, generator=g).to(torch.bfloat16)
+    dy = torch.randn(B, h, h, co, device=dev, generator=g).to(torch.bfloat16)
+    xf, dyf = x.float(), dy.float()
+    if k == 1:
+        ref = torch.einsum("nhwo,nhwi->oi", dyf, xf)[:, None, :]
+    else:
+        xp = F.pad(xf, (0, 0, 1, 1, 1, 1))
+        ref = torch.stack([torch.einsum("nhwo,nhwi->oi", dyf, xp[:, t // 3:t // 3 + h, t % 3:t % 3 + h, :]) for t in range(9)], 1)
+    scale = ref.abs().max().item()
+    ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    old = (ops.WGRAD_FORM, ops.WGRAD_FORM_ARG, ops.WGRAD_ROW_BLOCKS)
+    try:
+        for form, use_ws, blocks in ((0, False, 0), (0, True, 128), (2, False, 0), (4, False, 0), (5, False, 0), (5, True, 0), (5, True, 96)):
+            ops.WGRAD_FORM, ops.WGRAD_FORM_ARG = form, (blocks if form == 5 else 0)
+            ops.WGRAD_ROW_BLOCKS = blocks
+            dw = torch.zeros(co, k * k, ci, device=dev)
+            ops.conv_wgrad(x, dy, dw, k, 1, ws=ws if use_ws else None)
+            torch.cuda.synchronize()
+            err = (dw - ref).abs().max().item()
+            assert err <= 2e-5 * scale, (form, use_ws, blocks, ops.L.load().mgd_last_kernel(), err / scale)
+    finally:
+        ops.WGRAD_FORM, ops.WGRAD_FORM_ARG, ops.WGRAD_ROW_BLOCKS = old
