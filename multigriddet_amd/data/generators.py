@@ -495,7 +495,8 @@ class MultiGridDataGenerator:
         th = threading.Thread(target=produce, name="mgd-prefetch", daemon=True)
         th.start()
         if not hasattr(self, "_copy_stream"):
-            self._copy_stream = torch.cuda.Stream()
+            from ..streams import shared_stream
+            self._copy_stream = shared_stream("copy")     # one per process and device, whatever the number of generators
         cs = self._copy_stream
 
         def upload():

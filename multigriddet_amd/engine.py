@@ -13,6 +13,8 @@ import math
 import numpy as np
 import torch
 
+from .streams import shared_stream
+
 from . import _lib as L
 from . import ops
 from . import ops32
@@ -156,7 +158,7 @@ class Network:
         # they run on a side stream and fill the CUs that the small / tail-heavy kernels of the dgrad -> BN chain
         # leave idle.  Needs one dy buffer per layer (no scratch reuse while a side-stream wgrad may read it).
         self.overlap_wgrad = True
-        self.wg_stream = torch.cuda.Stream(device=dev)
+        self.wg_stream = shared_stream("wgrad", dev)      # one per process and device (streams.py: hardware queues are few)
         self.side_bias_grad = True      # bias gradients of the prediction convs ride on the weight-gradient side stream
         self.fuse_stem_bn = not self.fp32        # stem: BN backward applied inside the weight-gradient kernel (dy0 never written)
         self.fuse_bn_reduce = not self.fp32      # BN-backward reduction inside the dgrad epilogue that produces `da` (A/B: 0.9 ms/step faster)

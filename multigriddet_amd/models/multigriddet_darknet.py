@@ -117,7 +117,8 @@ class MultiGridDetModel:
             # graphs from one stream at a time.
             cs = getattr(self, "_capture_stream", None)
             if cs is None:
-                cs = self._capture_stream = torch.cuda.Stream(self.net.device)
+                from ..streams import shared_stream
+                cs = self._capture_stream = shared_stream("capture", self.net.device)
             with torch.cuda.stream(cs):
                 self.net.latency_workspace()
             torch.cuda.synchronize()

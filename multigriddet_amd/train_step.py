@@ -9,6 +9,8 @@ one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI), gra
 import os
 
 import torch
+
+from .streams import shared_stream
 import torch.distributed as dist
 
 from . import ops
@@ -37,7 +39,7 @@ class TrainStep:
         self.v = torch.zeros_like(net.params) if optimizer in ("adam", "adamw") else None
         self._loss = {}
         self._douts = {}
-        self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
+        self.comm_stream = shared_stream("comm", dev) if world_size > 1 else None
         cabi = None
         if world_size > 1 and os.environ.get("MGD_DP_COMM", "torch") == "cabi":
             import torch.distributed as dist
@@ -49,7 +51,7 @@ class TrainStep:
         # bucket's all-reduce, under the rest of backward - no serial optimiser tail after the last collective
         self.bucket_optimizer = True
         self._bucket_packs = {}
-        self.main_stream = torch.cuda.Stream(device=dev, priority=-1)
+        self.main_stream = shared_stream("main", dev, priority=-1)
         # hipGraph replay of the whole step (single process, Adam/AdamW): see enable_graph()
         self.use_graph = False
         self.early_optimizer = True     # see _step_body

@@ -583,3 +583,20 @@ def test_two_models_on_two_streams_share_no_latency_state():
         with torch.cuda.stream(s):
             for ws in models[i].net._lat_ws.values():
                 assert not ws.tickets().any()
+
+
+def test_streams_are_one_per_role_and_device():
+    """multigriddet_amd/streams.py: every Network of the process runs its weight gradients on the same side stream and every
+    TrainStep on the same high-priority main stream (hardware queues are few: a stream per object makes streams share queues,
+    and the two-stream backward serialises)."""
+    from multigriddet_amd.engine import Network
+    from multigriddet_amd.streams import shared_stream
+    from multigriddet_amd.train_step import TrainStep
+    from conftest import coco_anchors
+    dev = torch.device("cuda:0")
+    n1, n2 = Network(4, 3, dev, seed=0), Network(4, 3, dev, seed=1)
+    assert n1.wg_stream is n2.wg_stream is shared_stream("wgrad", dev)
+    t1 = TrainStep(n1, coco_anchors(), 4, (128, 128), 2, lr=1e-4)
+    t2 = TrainStep(n2, coco_anchors(), 4, (128, 128), 2, lr=1e-4)
+    assert t1.main_stream is t2.main_stream and t1.main_stream is not n1.wg_stream
+    assert t1.main_stream.priority < n1.wg_stream.priority or t1.main_stream.priority == -1

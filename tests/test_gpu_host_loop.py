@@ -434,7 +434,13 @@ def test_prefetching_generator_hides_the_host_path(tmp_path):
     for (xa, _), (xb, _), (xc, _) in zip(a, b, c):
         for ta, tb_, tc_ in zip(xa, xb, xc):
             assert torch.equal(ta, tb_) and torch.equal(ta, tc_)
-    b.close()
+    for gq in (a, b, c):                               # no loader of part (1) left running beside the timed steps
+        gq.close()
+    # (b, c and the generators below all upload on THE copy stream of the process - multigriddet_amd/streams.py.  With a copy
+    # stream per generator this process held six streams on four hardware queues, the weight-gradient stream shared a queue
+    # with the main stream, and every step - synthetic or fed - took 14.6 ms instead of 11.9.)
+    from multigriddet_amd.streams import shared_stream
+    assert b._copy_stream is c._copy_stream is shared_stream("copy")
     # (2) timing
     dev = torch.device("cuda:0")
     net = Network(80, 3, dev, seed=0)
