@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from PIL import Image
 import multigriddet_amd.data.generators as G
 class FakeStream:
+    def __init__(self, device=None, priority=0): pass
     def __enter__(self): return self
     def __exit__(self,*a): return False
 class FakeEvent:
