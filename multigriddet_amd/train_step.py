@@ -55,6 +55,7 @@ class TrainStep:
         # hipGraph replay of the whole step (single process, Adam/AdamW): see enable_graph()
         self.use_graph = False
         self.early_optimizer = True     # see _step_body
+        self.targets_on_side_stream = True   # build_targets on the weight-gradient stream, under the forward pass
         self._graphs = {}
         self._hyper = torch.zeros(2, dtype=torch.float32, device=dev)
         # launch plan (enable_plan): the step's ~600 C-ABI calls recorded once, replayed by mgd_plan_run without the interpreter
@@ -222,10 +223,26 @@ class TrainStep:
                 need = ops.L.load().mgd_build_targets_workspace_size(B, boxes.shape[1], len(ys),
                                                                      (ops.C.c_int32 * (2 * len(ys)))(*[int(v) for g in self._grids(H, W) for v in g]))
                 tout = self._targets[tkey] = (ys, torch.empty(need, dtype=torch.uint8, device=boxes.device))
-            y_true = ops.build_targets(boxes if boxes.is_contiguous() else boxes.contiguous(), (H, W), self.anchors, self.num_classes,
-                                       self._grids(H, W), mode=self.target_mode, out=tout)
+            bxs = boxes if boxes.is_contiguous() else boxes.contiguous()
+        else:
+            bxs = None
+        # Work the forward pass does not depend on goes to the weight-gradient stream, which is idle until the first data
+        # gradient exists: the targets (needed by the loss only) and the zeroing of the 250-MB gradient buffer (its last
+        # reader, the optimiser of the previous step, is behind us on the main stream).  The main stream joins before the loss.
+        side = net.wg_stream if (self.targets_on_side_stream and net.overlap_wgrad) else None
+        if side is not None:
+            ops.stream_wait(side)
+            with torch.cuda.stream(side):
+                if bxs is not None:
+                    y_true = ops.build_targets(bxs, (H, W), self.anchors, self.num_classes, self._grids(H, W), mode=self.target_mode, out=tout)
+                net.zero_grad()
+        elif bxs is not None:
+            y_true = ops.build_targets(bxs, (H, W), self.anchors, self.num_classes, self._grids(H, W), mode=self.target_mode, out=tout)
         outs = net.forward(images)
-        net.zero_grad()
+        if side is not None:
+            ops.stream_wait(torch.cuda.current_stream(), side)
+        else:
+            net.zero_grad()
         runner, douts = self._loss_runner(B, H, W)
         comp = runner.run(y_true, outs, **({"grad_f32": douts} if net.fp32 else {"grad_bf16": douts}))
         if self.world > 1:
