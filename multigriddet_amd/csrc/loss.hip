@@ -479,14 +479,29 @@ __global__ __launch_bounds__(256) void loss_cell2_kernel(LossArgs a) {
           iou_a[j] = fmaxf(fmaxf(part[0][j][ci], part[1][j][ci]), fmaxf(part[2][j][ci], part[3][j][ci]));
           max_iou = j == 0 ? iou_a[0] : fmaxf(max_iou, iou_a[j]);
         }
-      const float t_x = t[0], t_y = t[1], t_w = t[2], t_h = t[3], tob = t[4];
+      // the cell's 5 + A header values of both tensors: two 16-byte loads each when the row pitch keeps them aligned (they are
+      // 352 bytes apart from lane to lane: every dword load of a wave touches 64 cache lines)
+      float th_[8], ph_[8];
+      if ((F & 3) == 0 && A <= 3 && ((((unsigned long long)t) | ((unsigned long long)p)) & 15ull) == 0) {
+        const float4 t0 = ((const float4*)t)[0], t1 = ((const float4*)t)[1];
+        const float4 p1 = ((const float4*)p)[1];
+        th_[0] = t0.x; th_[1] = t0.y; th_[2] = t0.z; th_[3] = t0.w; th_[4] = t1.x; th_[5] = t1.y; th_[6] = t1.z; th_[7] = t1.w;
+        ph_[4] = p1.x; ph_[5] = p1.y; ph_[6] = p1.z; ph_[7] = p1.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          th_[j] = j < 5 + A ? t[j] : 0.f;
+          ph_[j] = (j >= 4 && j < 5 + A) ? p[j] : 0.f;
+        }
+      }
+      const float t_x = th_[0], t_y = th_[1], t_w = th_[2], t_h = th_[3], tob = th_[4];
       obj = tob > 0.5f ? 1.f : 0.f;
       const float ignore = (max_iou > c.ignore_thresh && tob < 0.5f) ? 1.f : 0.f;
       float tanc[MAXA], panc[MAXA];
 #pragma unroll
       for (int j = 0; j < MAXA; ++j) {
-        tanc[j] = j < A ? t[5 + j] : 0.f;
-        panc[j] = j < A ? p[5 + j] : 0.f;
+        tanc[j] = j < A ? (j < 3 ? th_[5 + j] : t[5 + j]) : 0.f;
+        panc[j] = j < A ? (j < 3 ? ph_[5 + j] : p[5 + j]) : 0.f;
       }
       int kstar = 0;
       {
@@ -526,7 +541,7 @@ __global__ __launch_bounds__(256) void loss_cell2_kernel(LossArgs a) {
         g[3] = c.coord_scale * obj * 2.f * dh * inv_nf;
       }
       {
-        const float pob = p[4];
+        const float pob = ph_[4];
         s_obj += bce_logits(tgt, pob) * wobj;
         g[4] = c.object_scale * wobj * (sigmoidf(pob) - tgt) * inv_nf;
       }
@@ -551,8 +566,10 @@ __global__ __launch_bounds__(256) void loss_cell2_kernel(LossArgs a) {
   }
   __syncthreads();
 
-  // ---- B: class channels, element (cell, class) = e / C, e % C
+  // ---- B: class channels, element (cell, class) = e / C, e % C.  U elements per thread and round, all of their loads issued
+  // before the first is used: one element per round was one dependent memory round trip per element (20 per thread).
   {
+    constexpr int U = 4;
     const int nel = ncell * C;
     const int dq = 256 / C, dr = 256 - dq * C;
     int cell = tid / C, k = tid - cell * C;
@@ -560,33 +577,46 @@ __global__ __launch_bounds__(256) void loss_cell2_kernel(LossArgs a) {
     const float* Tc = T + 5 + A;
     float* gfc = a.gf[l] ? a.gf[l] + cell0 * F + 5 + A : nullptr;
     bf16_t* gbc = a.gb[l] ? a.gb[l] + cell0 * F + 5 + A : nullptr;
-    for (int e = tid; e < nel; e += 256) {
-      const long long off = (long long)cell * F + k;
-      const float pv = Pc[off], tv = Tc[off];
-      const float obj = cell_obj[cell];
-      const float cw = a.class_w ? a.class_w[k] : 1.f;
-      float gout;
-      if (c.use_focal_loss) {
-        const float pr = sigmoidf(pv);
-        const float pt = tv * pr + (1.f - tv) * (1.f - pr);
-        const float om = fmaxf(1.f - pt, 0.f);
-        const float mod = powf(om, c.focal_gamma);
-        const float at = tv * c.focal_alpha + (1.f - tv) * (1.f - c.focal_alpha);
-        const float bce = bce_logits(tv, pv);
-        s_cls += mod * at * bce * cw * obj;
-        const float dmod = om > 0.f ? -c.focal_gamma * powf(om, c.focal_gamma - 1.f) * (2.f * tv - 1.f) * pr * (1.f - pr) : 0.f;
-        gout = c.class_scale * cw * obj * at * (dmod * bce + mod * (pr - tv)) * inv_nf;
-      } else {
-        const float ts = c.label_smoothing > 0.f ? tv * (1.f - c.label_smoothing) + c.label_smoothing / (float)C : tv;
-        s_cls += bce_logits(ts, pv) * cw * obj;
-        gout = c.class_scale * cw * obj * (sigmoidf(pv) - ts) * inv_nf;
+    for (int e0 = tid; e0 < nel; e0 += 256 * U) {
+      long long off[U];
+      int kk[U], cc[U];
+      float pv[U], tv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        cc[u] = cell; kk[u] = k;
+        off[u] = (long long)cell * F + k;
+        const bool ok = e0 + u * 256 < nel;
+        pv[u] = ok ? Pc[off[u]] : 0.f;
+        tv[u] = ok ? Tc[off[u]] : 0.f;
+        cell += dq;
+        k += dr;
+        if (k >= C) { k -= C; ++cell; }
       }
-      gout *= gscale;
-      if (gfc) gfc[off] = gout;
-      if (gbc) gbc[off] = f2bf(gout);
-      cell += dq;
-      k += dr;
-      if (k >= C) { k -= C; ++cell; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (e0 + u * 256 >= nel) break;
+        const float obj = cell_obj[cc[u]];
+        const float cw = a.class_w ? a.class_w[kk[u]] : 1.f;
+        float gout;
+        if (c.use_focal_loss) {
+          const float pr = sigmoidf(pv[u]);
+          const float pt = tv[u] * pr + (1.f - tv[u]) * (1.f - pr);
+          const float om = fmaxf(1.f - pt, 0.f);
+          const float mod = powf(om, c.focal_gamma);
+          const float at = tv[u] * c.focal_alpha + (1.f - tv[u]) * (1.f - c.focal_alpha);
+          const float bce = bce_logits(tv[u], pv[u]);
+          s_cls += mod * at * bce * cw * obj;
+          const float dmod = om > 0.f ? -c.focal_gamma * powf(om, c.focal_gamma - 1.f) * (2.f * tv[u] - 1.f) * pr * (1.f - pr) : 0.f;
+          gout = c.class_scale * cw * obj * at * (dmod * bce + mod * (pr - tv[u])) * inv_nf;
+        } else {
+          const float ts = c.label_smoothing > 0.f ? tv[u] * (1.f - c.label_smoothing) + c.label_smoothing / (float)C : tv[u];
+          s_cls += bce_logits(ts, pv[u]) * cw * obj;
+          gout = c.class_scale * cw * obj * (sigmoidf(pv[u]) - ts) * inv_nf;
+        }
+        gout *= gscale;
+        if (gfc) gfc[off[u]] = gout;
+        if (gbc) gbc[off[u]] = f2bf(gout);
+      }
     }
   }
   s_loc = wave_sum(s_loc); s_obj = wave_sum(s_obj); s_anc = wave_sum(s_anc); s_cls = wave_sum(s_cls);
