@@ -113,10 +113,10 @@ def infer_bench(dev, size, steps=20, warmup=3):
     dec = MultiGridDecoder(coco_anchors(), 80, (size, size))
     kw = dict(max_boxes=100, confidence=0.008, nms_threshold=0.45, nms_method="diou")
     runs = []
-    for batch in (16, 1):
+    for batch, folds in ((16, (False, True)), (1, (False, True)), (32, (True,))):       # batch 32: what a batched service would run
         img = torch.from_numpy(np.random.default_rng(0).random((batch, size, size, 3), dtype=np.float32)).to(dev)
         shapes = [(480, 640)] * batch
-        for fold in (False, True):
+        for fold in folds:
             model.fold_bn(fold)
             for _ in range(warmup):
                 r = dec.postprocess_batch(model(img, training=False), shapes, **kw)
