@@ -8,6 +8,15 @@
 
 namespace {
 
+// 16-byte load with the non-temporal hint for operands the BatchNorm passes stream once (they are dead afterwards: no reason to
+// keep their lines in L2 / the memory-side cache beside the tensors the next kernel reads; 11.70 -> 11.63 ms per step, same box.
+// The same hint on the optimiser's 1.2 GB per step measured nothing.)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load16(const void* p) {
+  const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 // Sum of the R replicas of a per-channel pair (stats[r][0][c], stats[r][1][c]), replicas in ascending order (same
 // rounding as the plain loop).  The loads of eight replicas are issued before the first add: written as a plain
 // `for r: s += stats[r]` loop the compiler kept one load in flight at a time and the 16-replica fold cost ~8 us of
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_fused_kernel(const float* __re
       long long p = p0 + u * stride;
       if (p < P) {
         long long e = p * C + oct * 8;
-        yv[u] = *(const uint4*)(y + e);
+        yv[u] = nt_load16(y + e);     // y is dead after this pass (until the backward pass)
         if (res) rv[u] = *(const uint4*)(res + e);
       }
     }
@@ -232,8 +241,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
       long long p = p0 + u * stride;
       if (p < P) {
         long long e = p * C + oct * 8;
-        gv[u] = *(const uint4*)(da + e);
-        yv[u] = *(const uint4*)(y + e);
+        gv[u] = nt_load16(da + e);    // both operands are dead after this pass
+        yv[u] = nt_load16(y + e);
       }
     }
   };
